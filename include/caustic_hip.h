@@ -1,0 +1,177 @@
+/* caustic_hip.h — C ABI of libcaustic_hip.so, the MI355X (gfx950) render path for
+ * the scene vocabulary of the reference's crates/core.
+ *
+ * The reference has no FFI layer: its seam is the Rust call
+ *   Camera::render(&self, ctx, x, y, world: &dyn Node, lights) -> Color   (crates/core/src/camera.rs:324-331)
+ * over SceneData{camera, world, lights} (crates/core/src/lib.rs:38-43), driven per pixel by
+ * crates/cli/src/main.rs:136-146 and per rectangle by crates/wasm/src/lib.rs:215-242.
+ * A GPU backend replaces the block/frame loop, so this ABI is "build the same scene
+ * graph through the same constructors, then render a rectangle / frame".
+ *
+ * Conventions: every input is copied at call time (the caller keeps ownership);
+ * outputs go to caller-allocated buffers; geometry crosses the ABI as double
+ * because the reference is f64 end to end.  Functions returning int give
+ * >= 0 (an id, or 0 for success) or < 0 on error, with the message available from
+ * chip_last_error() on the calling thread.  Ids are creation-order integers per
+ * category (textures, materials, nodes).  A scene may be used from one host
+ * thread at a time; distinct scenes are independent.  The random stream is an
+ * internal counter-based Philox4x32-10 keyed on (seed, pixel, stratum, bounce),
+ * replacing RenderContext.random (crates/core/src/lib.rs:34-36).
+ */
+#ifndef CAUSTIC_HIP_H
+#define CAUSTIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct chip_scene chip_scene;
+
+/* CameraBuilder's public fields, crates/core/src/camera.rs:34-89 (defaults :106-120). */
+typedef struct chip_camera_desc {
+  double vertical_fov;
+  double aspect_ratio;
+  uint32_t image_width;
+  uint32_t reserved0;
+  double look_from[3];
+  double look_at[3];
+  double up[3];
+  double defocus_angle;
+  double focus_distance;
+  uint32_t samples_per_pixel;
+  uint32_t max_depth;
+  double background[3];
+} chip_camera_desc;
+
+/* What one render call covers.  The strata of camera.rs:335-341 are numbered
+ * s = s_y * sqrt_spp + s_x; this call renders those with s % stratum_stride ==
+ * stratum_offset (offset 0 / stride 1 = all of them), which is how samples are
+ * split over GPUs.  The rectangle is [xmin,xmax) x [ymin,ymax) as in
+ * crates/wasm/src/lib.rs:215; xmax == ymax == 0 means the whole image. */
+typedef struct chip_render_opts {
+  uint64_t seed;
+  uint32_t stratum_offset;
+  uint32_t stratum_stride;
+  uint32_t xmin, xmax, ymin, ymax;
+  uint32_t strata_per_batch; /* 0 = choose from the path-pool capacity */
+  uint32_t flags;            /* CHIP_RENDER_* bits */
+} chip_render_opts;
+
+/* HitRecord of crates/core/src/object/mod.rs:31-39 for chip_trace_rays. */
+typedef struct chip_hit {
+  double t;
+  double pt[3];
+  double normal[3];
+  double u, v;
+  int32_t hit;           /* 0 = miss */
+  int32_t leaf_id;       /* node id of the primitive / box / medium that produced the record */
+  int32_t front_face;
+  int32_t material_kind; /* CHIP_MAT_* */
+} chip_hit;
+
+typedef struct chip_stats {
+  uint64_t paths;      /* camera samples traced */
+  uint64_t segments;   /* world.hit calls (ray segments) */
+  uint64_t bvh_visits; /* BVH nodes whose box was tested */
+  uint64_t prim_tests; /* sphere / quad intersection tests */
+  double ms_total;     /* device time of the whole call (HIP events) */
+  double ms_trace;     /* sum of the traversal kernel's launch durations (HIP events; only with CHIP_RENDER_TIME_KERNELS) */
+  double ms_shade;     /* same for the shade kernels */
+  double ms_other;
+  uint64_t trace_launches; /* traversal kernel launches in this call */
+  uint64_t batches;        /* path-pool batches in this call */
+} chip_stats;
+
+enum { CHIP_RENDER_TIME_KERNELS = 1 /* bracket traversal / shade launches with HIP events and report their durations */ };
+enum { CHIP_MAT_LAMBERTIAN = 0, CHIP_MAT_METAL = 1, CHIP_MAT_DIELECTRIC = 2, CHIP_MAT_DIFFUSE_LIGHT = 3, CHIP_MAT_ISOTROPIC = 4, CHIP_MAT_EMPTY = 5 };
+/* node kinds reported by chip_dump_tree */
+enum { CHIP_NODE_BVH = 0, CHIP_NODE_SPHERE = 1, CHIP_NODE_QUAD = 2, CHIP_NODE_GROUP = 3, CHIP_NODE_TRANSLATE = 4, CHIP_NODE_ROTATE = 5, CHIP_NODE_MEDIUM = 6, CHIP_NODE_BOX = 7 };
+
+const char* chip_last_error(void);
+/* Number of HIP devices visible; < 0 when the HIP runtime cannot be initialised. */
+int chip_device_count(void);
+
+chip_scene* chip_scene_create(void);
+void chip_scene_destroy(chip_scene* s);
+
+/* Textures: crates/core/src/texture/ (all files) */
+int chip_tex_solid(chip_scene* s, double r, double g, double b);             /* solid_color.rs:14-17 */
+int chip_tex_checker(chip_scene* s, double scale, int even, int odd);         /* checker_texture.rs:13-35 */
+int chip_tex_image(chip_scene* s, uint32_t w, uint32_t h, const uint8_t* rgb); /* image_texture.rs:16-29, image.rs:58-66 */
+/* Perlin tables (utils/perlin.rs:27-36) are passed in, so the caller's RNG decides them as in
+ * Perlin::new(random): rand_vec = 256 x 3 doubles, perm_* = 256 int32 each. */
+int chip_tex_perlin_noise(chip_scene* s, double scale, const double* rand_vec, const int32_t* perm_x, const int32_t* perm_y,
+                          const int32_t* perm_z); /* perlin_noise.rs:18-22 */
+int chip_tex_perlin_turbulence(chip_scene* s, double scale, uint32_t depth, const double* rand_vec, const int32_t* perm_x,
+                               const int32_t* perm_y, const int32_t* perm_z); /* perlin_turbulence.rs:20-27 */
+
+/* Materials: crates/core/src/material/ (all files) */
+int chip_lambertian_color(chip_scene* s, double r, double g, double b); /* lambertian.rs:21-25 */
+int chip_lambertian_tex(chip_scene* s, int tex);                         /* lambertian.rs:17-19 */
+int chip_metal(chip_scene* s, double r, double g, double b, double fuzz); /* metal.rs:14-16 */
+int chip_dielectric(chip_scene* s, double refraction_index);             /* dielectric.rs:17-19 */
+int chip_diffuse_light_color(chip_scene* s, double r, double g, double b); /* diffuse_light.rs:20-24 */
+int chip_diffuse_light_tex(chip_scene* s, int tex);                        /* diffuse_light.rs:16-18 */
+int chip_empty_material(chip_scene* s);                                    /* empty.rs:7-9 */
+
+/* Nodes: crates/core/src/object/ (all files) */
+int chip_sphere(chip_scene* s, const double center[3], double radius, int mat);            /* sphere.rs:21-29 */
+/* Only before the sphere is referenced by another node (Rust mutates before Arc::new). */
+int chip_sphere_set_direction(chip_scene* s, int node, const double direction[3]);         /* sphere.rs:31-34 */
+int chip_quad(chip_scene* s, const double q[3], const double u[3], const double v[3], int mat); /* quad.rs:59-76 */
+int chip_box(chip_scene* s, const double a[3], const double b[3], int mat);                /* box_node.rs:15-74 */
+int chip_group(chip_scene* s, const int32_t* nodes, int n);                                /* group.rs:22-34 */
+int chip_bvh(chip_scene* s, const int32_t* nodes, int n);                                  /* bounding_volume_hierarchy.rs:16-46 */
+int chip_translate(chip_scene* s, int node, const double offset[3]);                       /* translate.rs:15-22 */
+int chip_rotate(chip_scene* s, int node, const double axis[3], double angle_degrees);      /* rotate.rs:19-79 */
+int chip_constant_medium_color(chip_scene* s, int boundary, double density, double r, double g, double b); /* constant_medium.rs:31-37 */
+int chip_constant_medium_tex(chip_scene* s, int boundary, double density, int tex);        /* constant_medium.rs:19-29 */
+
+/* SceneData, crates/core/src/lib.rs:38-43; lights < 0 = None. */
+int chip_scene_set_world(chip_scene* s, int node);
+int chip_scene_set_lights(chip_scene* s, int node);
+int chip_scene_set_camera(chip_scene* s, const chip_camera_desc* desc); /* CameraBuilder::build, camera.rs:126-182 */
+
+/* Flatten the scene graph into device buffers on the current HIP device. */
+int chip_commit(chip_scene* s);
+int chip_image_size(chip_scene* s, uint32_t* width, uint32_t* height); /* camera.rs:397-404 */
+int chip_sqrt_spp(chip_scene* s);                                       /* camera.rs:131 */
+/* The derived Camera fields of camera.rs:166-181 as 24 doubles: center, pixel00_loc, pixel_delta_u,
+ * pixel_delta_v, defocus_disk_u, defocus_disk_v, then pixel_samples_scale, reciprocal_sqrt_spp,
+ * defocus_angle, sqrt_spp, image_width, image_height. */
+int chip_camera_derived(chip_scene* s, double* out24);
+
+/* Replaces the caller loop of crates/cli/src/main.rs:119-186 (and one call of crates/wasm/src/lib.rs:215-242
+ * per rectangle).  out_sum_rgb (host, rect_w*rect_h*3 floats, nullable) receives the un-normalised
+ * linear radiance sum over the strata rendered by this call (NaN preserved, camera.rs:339);
+ * out_rgb8 (host, nullable) receives camera.rs:343-344 + main.rs:193-198 applied to that sum with
+ * the full pixel_samples_scale, i.e. it is the final image only when all strata were rendered. */
+int chip_render_frame(chip_scene* s, const chip_render_opts* opts, float* out_sum_rgb, uint8_t* out_rgb8, chip_stats* stats);
+/* Same, but the sum is ADDED into a device buffer the caller owns (float, rect_w*rect_h*3, on the
+ * current device) and nothing is copied to the host: the form used when an external collective
+ * reduces per-GPU sums.  Work is queued on `stream` (a hipStream_t, NULL = default stream) and
+ * the call returns after that work completed. */
+int chip_render_accumulate_device(chip_scene* s, const chip_render_opts* opts, float* d_sum_rgb, void* stream, chip_stats* stats);
+/* camera.rs:343-344 (+ main.rs:193-198 when out_rgb8 is set) on a device sum buffer; out_gamma /
+ * out_rgb8 are device pointers, either nullable. */
+int chip_resolve_device(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, void* stream);
+
+/* Test hooks.  chip_trace_rays: closest hit of world over [0.001, inf) (camera.rs:264) for n host
+ * rays (origin, direction: n x 3 doubles; time: n doubles or NULL = 0).  Medium free-flight draws
+ * use the Philox stream keyed (seed, ray index, 0, bounce 0). */
+int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* origin, const double* direction, const double* time,
+                    chip_hit* out);
+/* Camera rays of camera.rs:359-374 for n (x, y, s_x, s_y) tuples; rays = n x 7 doubles. */
+int chip_camera_rays(chip_scene* s, uint64_t seed, size_t n, const uint32_t* xyss, double* rays);
+/* Preorder dump of the host scene tree (BVH: left then right): node kind, creation id (-1 for
+ * nodes built internally), bbox as xmin,xmax,ymin,ymax,zmin,zmax.  Returns the record count,
+ * which may exceed cap (then only cap records were written). */
+int64_t chip_dump_tree(chip_scene* s, int32_t* kinds, int32_t* ids, double* boxes, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAUSTIC_HIP_H */

@@ -1,0 +1,446 @@
+"""ctypes bindings over the C ABI of include/caustic_hip.h.
+
+`Backend` wraps one shared library that exports the scene vocabulary of the
+reference's crates/core (sphere, quad, box, group, bvh, translate, rotate,
+constant medium, materials, textures, camera) under a function-name prefix.
+The product library (`libcaustic_hip.so`, prefix ``chip_``) is loaded with
+`load_gpu()`; it has no CPU fallback and raises if the library or a HIP device
+is missing.  The same wrapper class is reused by the test suite for the CPU
+oracle, which exports the same vocabulary under another prefix.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GPU_LIB_PATH = os.path.join(_HERE, "libcaustic_hip.so")
+
+
+class CameraDesc(C.Structure):
+    """CameraBuilder's fields, crates/core/src/camera.rs:34-89 (defaults :106-120)."""
+
+    _fields_ = [
+        ("vertical_fov", C.c_double),
+        ("aspect_ratio", C.c_double),
+        ("image_width", C.c_uint32),
+        ("reserved0", C.c_uint32),
+        ("look_from", C.c_double * 3),
+        ("look_at", C.c_double * 3),
+        ("up", C.c_double * 3),
+        ("defocus_angle", C.c_double),
+        ("focus_distance", C.c_double),
+        ("samples_per_pixel", C.c_uint32),
+        ("max_depth", C.c_uint32),
+        ("background", C.c_double * 3),
+    ]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("stratum_offset", C.c_uint32),
+        ("stratum_stride", C.c_uint32),
+        ("xmin", C.c_uint32),
+        ("xmax", C.c_uint32),
+        ("ymin", C.c_uint32),
+        ("ymax", C.c_uint32),
+        ("strata_per_batch", C.c_uint32),
+        ("flags", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("paths", C.c_uint64),
+        ("segments", C.c_uint64),
+        ("bvh_visits", C.c_uint64),
+        ("prim_tests", C.c_uint64),
+        ("ms_total", C.c_double),
+        ("ms_trace", C.c_double),
+        ("ms_shade", C.c_double),
+        ("ms_other", C.c_double),
+        ("trace_launches", C.c_uint64),
+        ("batches", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+HIT_DTYPE = np.dtype(
+    [
+        ("t", "<f8"),
+        ("pt", "<f8", (3,)),
+        ("normal", "<f8", (3,)),
+        ("u", "<f8"),
+        ("v", "<f8"),
+        ("hit", "<i4"),
+        ("leaf_id", "<i4"),
+        ("front_face", "<i4"),
+        ("material_kind", "<i4"),
+    ]
+)
+assert HIT_DTYPE.itemsize == 88
+
+RENDER_TIME_KERNELS = 1
+
+NODE_KIND_NAMES = {0: "bvh", 1: "sphere", 2: "quad", 3: "group", 4: "translate", 5: "rotate", 6: "medium", 7: "box"}
+
+
+class CausticError(RuntimeError):
+    pass
+
+
+def _vec3(v):
+    return (C.c_double * 3)(float(v[0]), float(v[1]), float(v[2]))
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Backend:
+    """One loaded library exporting `<prefix>scene_create`, `<prefix>sphere`, ..."""
+
+    def __init__(self, lib: C.CDLL, prefix: str, name: str):
+        self.lib = lib
+        self.prefix = prefix
+        self.name = name
+        self._declare()
+
+    def fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def _declare(self):
+        d = C.c_double
+        i = C.c_int
+        p = C.c_void_p
+        pd = C.POINTER(C.c_double)
+        pi32 = C.POINTER(C.c_int32)
+        sigs = {
+            "last_error": (C.c_char_p, []),
+            "scene_create": (p, []),
+            "scene_destroy": (None, [p]),
+            "tex_solid": (i, [p, d, d, d]),
+            "tex_checker": (i, [p, d, i, i]),
+            "tex_image": (i, [p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]),
+            "tex_perlin_noise": (i, [p, d, pd, pi32, pi32, pi32]),
+            "tex_perlin_turbulence": (i, [p, d, C.c_uint32, pd, pi32, pi32, pi32]),
+            "lambertian_color": (i, [p, d, d, d]),
+            "lambertian_tex": (i, [p, i]),
+            "metal": (i, [p, d, d, d, d]),
+            "dielectric": (i, [p, d]),
+            "diffuse_light_color": (i, [p, d, d, d]),
+            "diffuse_light_tex": (i, [p, i]),
+            "empty_material": (i, [p]),
+            "sphere": (i, [p, pd, d, i]),
+            "sphere_set_direction": (i, [p, i, pd]),
+            "quad": (i, [p, pd, pd, pd, i]),
+            "box": (i, [p, pd, pd, i]),
+            "group": (i, [p, pi32, i]),
+            "bvh": (i, [p, pi32, i]),
+            "translate": (i, [p, i, pd]),
+            "rotate": (i, [p, i, pd, d]),
+            "constant_medium_color": (i, [p, i, d, d, d, d]),
+            "constant_medium_tex": (i, [p, i, d, i]),
+            "scene_set_world": (i, [p, i]),
+            "scene_set_lights": (i, [p, i]),
+            "scene_set_camera": (i, [p, C.POINTER(CameraDesc)]),
+            "commit": (i, [p]),
+            "image_size": (i, [p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+            "sqrt_spp": (i, [p]),
+            "camera_derived": (i, [p, pd]),
+            "trace_rays": (i, [p, C.c_uint64, C.c_size_t, pd, pd, pd, p]),
+            "camera_rays": (i, [p, C.c_uint64, C.c_size_t, C.POINTER(C.c_uint32), pd]),
+            "dump_tree": (C.c_int64, [p, pi32, pi32, pd, C.c_size_t]),
+            "render_frame": (i, [p, C.POINTER(RenderOpts), p, C.POINTER(C.c_uint8), C.POINTER(Stats)]),
+        }
+        for name, (res, args) in sigs.items():
+            f = self.fn(name)
+            f.restype = res
+            f.argtypes = args
+        # entry points only the GPU library has
+        for name, (res, args) in {
+            "device_count": (i, []),
+            "render_accumulate_device": (i, [p, C.POINTER(RenderOpts), p, p, C.POINTER(Stats)]),
+            "resolve_device": (i, [p, p, C.c_size_t, p, p, p]),
+        }.items():
+            if hasattr(self.lib, self.prefix + name):
+                f = self.fn(name)
+                f.restype = res
+                f.argtypes = args
+
+    def last_error(self) -> str:
+        m = self.fn("last_error")()
+        return m.decode() if m else ""
+
+    def check(self, rc):
+        if rc < 0:
+            raise CausticError(f"{self.name}: {self.last_error()}")
+        return rc
+
+    def new_scene(self) -> "Scene":
+        return Scene(self)
+
+
+@dataclass
+class Scene:
+    """Handle-based builder mirroring crates/core's constructors; ids are creation-order ints."""
+
+    be: Backend
+    h: int = field(init=False)
+
+    def __post_init__(self):
+        self.h = self.be.fn("scene_create")()
+        if not self.h:
+            raise CausticError("scene_create failed")
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.be.fn("scene_destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        return self.be.check(self.be.fn(name)(self.h, *args))
+
+    # textures
+    def tex_solid(self, r, g, b):
+        return self._call("tex_solid", r, g, b)
+
+    def tex_checker(self, scale, even, odd):
+        return self._call("tex_checker", scale, even, odd)
+
+    def tex_image(self, rgb: np.ndarray):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w, c = rgb.shape
+        assert c == 3
+        return self._call("tex_image", w, h, _ptr(rgb, C.c_uint8))
+
+    def _perlin_args(self, tables):
+        rv = np.ascontiguousarray(tables["rand_vec"], dtype=np.float64)
+        px = np.ascontiguousarray(tables["perm_x"], dtype=np.int32)
+        py = np.ascontiguousarray(tables["perm_y"], dtype=np.int32)
+        pz = np.ascontiguousarray(tables["perm_z"], dtype=np.int32)
+        assert rv.shape == (256, 3) and px.shape == py.shape == pz.shape == (256,)
+        return rv, px, py, pz
+
+    def tex_perlin_noise(self, scale, tables):
+        rv, px, py, pz = self._perlin_args(tables)
+        return self._call("tex_perlin_noise", scale, _ptr(rv, C.c_double), _ptr(px, C.c_int32), _ptr(py, C.c_int32), _ptr(pz, C.c_int32))
+
+    def tex_perlin_turbulence(self, scale, depth, tables):
+        rv, px, py, pz = self._perlin_args(tables)
+        return self._call(
+            "tex_perlin_turbulence", scale, depth, _ptr(rv, C.c_double), _ptr(px, C.c_int32), _ptr(py, C.c_int32), _ptr(pz, C.c_int32)
+        )
+
+    # materials
+    def lambertian_color(self, r, g, b):
+        return self._call("lambertian_color", r, g, b)
+
+    def lambertian_tex(self, tex):
+        return self._call("lambertian_tex", tex)
+
+    def metal(self, r, g, b, fuzz):
+        return self._call("metal", r, g, b, fuzz)
+
+    def dielectric(self, ri):
+        return self._call("dielectric", ri)
+
+    def diffuse_light_color(self, r, g, b):
+        return self._call("diffuse_light_color", r, g, b)
+
+    def diffuse_light_tex(self, tex):
+        return self._call("diffuse_light_tex", tex)
+
+    def empty_material(self):
+        return self._call("empty_material")
+
+    # nodes
+    def sphere(self, center, radius, mat, direction=None):
+        n = self._call("sphere", _vec3(center), radius, mat)
+        if direction is not None:
+            self._call("sphere_set_direction", n, _vec3(direction))
+        return n
+
+    def sphere_set_direction(self, node, direction):
+        return self._call("sphere_set_direction", node, _vec3(direction))
+
+    def quad(self, q, u, v, mat):
+        return self._call("quad", _vec3(q), _vec3(u), _vec3(v), mat)
+
+    def box(self, a, b, mat):
+        return self._call("box", _vec3(a), _vec3(b), mat)
+
+    def _ids(self, nodes):
+        a = np.ascontiguousarray(nodes, dtype=np.int32)
+        return _ptr(a, C.c_int32), int(a.size), a
+
+    def group(self, nodes):
+        p, n, keep = self._ids(nodes)
+        return self._call("group", p, n)
+
+    def bvh(self, nodes):
+        p, n, keep = self._ids(nodes)
+        return self._call("bvh", p, n)
+
+    def translate(self, node, offset):
+        return self._call("translate", node, _vec3(offset))
+
+    def rotate(self, node, axis, degrees):
+        return self._call("rotate", node, _vec3(axis), degrees)
+
+    def rotate_y(self, node, degrees):  # rotate.rs:87-89
+        return self.rotate(node, (0.0, 1.0, 0.0), degrees)
+
+    def constant_medium_color(self, boundary, density, r, g, b):
+        return self._call("constant_medium_color", boundary, density, r, g, b)
+
+    def constant_medium_tex(self, boundary, density, tex):
+        return self._call("constant_medium_tex", boundary, density, tex)
+
+    # scene data
+    def set_world(self, node):
+        return self._call("scene_set_world", node)
+
+    def set_lights(self, node):
+        return self._call("scene_set_lights", -1 if node is None else node)
+
+    def set_camera(self, **kw):
+        d = CameraDesc()
+        d.vertical_fov = kw.get("vertical_fov", 90.0)
+        d.aspect_ratio = kw.get("aspect_ratio", 1.0)
+        d.image_width = kw.get("image_width", 100)
+        d.look_from = _vec3(kw.get("look_from", (0, 0, 0)))
+        d.look_at = _vec3(kw.get("look_at", (0, 0, -1)))
+        d.up = _vec3(kw.get("up", (0, 1, 0)))
+        d.defocus_angle = kw.get("defocus_angle", 0.0)
+        d.focus_distance = kw.get("focus_distance", 10.0)
+        d.samples_per_pixel = kw.get("samples_per_pixel", 10)
+        d.max_depth = kw.get("max_depth", 10)
+        d.background = _vec3(kw.get("background", (0, 0, 0)))
+        return self._call("scene_set_camera", C.byref(d))
+
+    def commit(self):
+        return self._call("commit")
+
+    def image_size(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        self._call("image_size", C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def sqrt_spp(self):
+        return self._call("sqrt_spp")
+
+    def camera_derived(self):
+        out = np.zeros(24, dtype=np.float64)
+        self._call("camera_derived", _ptr(out, C.c_double))
+        return out
+
+    # rendering
+    def _opts(self, seed=1, stratum_offset=0, stratum_stride=1, rect=None, strata_per_batch=0, flags=0):
+        o = RenderOpts()
+        o.seed = seed
+        o.stratum_offset = stratum_offset
+        o.stratum_stride = stratum_stride
+        if rect is not None:
+            o.xmin, o.xmax, o.ymin, o.ymax = rect
+        o.strata_per_batch = strata_per_batch
+        o.flags = flags
+        return o
+
+    def _rect_shape(self, rect):
+        w, h = self.image_size()
+        if rect is None:
+            return h, w
+        return rect[3] - rect[2], rect[1] - rect[0]
+
+    def render_frame(self, seed=1, stratum_offset=0, stratum_stride=1, rect=None, strata_per_batch=0, flags=0, want_rgb8=False, sum_dtype=np.float32):
+        """Returns (sum_rgb[h,w,3], rgb8 or None, stats dict).  sum_rgb is the un-normalised radiance sum."""
+        o = self._opts(seed, stratum_offset, stratum_stride, rect, strata_per_batch, flags)
+        rh, rw = self._rect_shape(rect)
+        out = np.zeros((rh, rw, 3), dtype=sum_dtype)
+        rgb8 = np.zeros((rh, rw, 3), dtype=np.uint8) if want_rgb8 else None
+        st = Stats()
+        self._call(
+            "render_frame",
+            C.byref(o),
+            out.ctypes.data_as(C.c_void_p),
+            _ptr(rgb8, C.c_uint8) if want_rgb8 else None,
+            C.byref(st),
+        )
+        return out, rgb8, st.as_dict()
+
+    def render_accumulate_device(self, d_sum_ptr: int, seed=1, stratum_offset=0, stratum_stride=1, rect=None, strata_per_batch=0, flags=0, stream=0):
+        """Adds this call's radiance sums into a device float buffer (rect_h*rect_w*3) owned by the caller."""
+        o = self._opts(seed, stratum_offset, stratum_stride, rect, strata_per_batch, flags)
+        st = Stats()
+        self._call("render_accumulate_device", C.byref(o), C.c_void_p(d_sum_ptr), C.c_void_p(stream), C.byref(st))
+        return st.as_dict()
+
+    def resolve_device(self, d_sum_ptr: int, npixels: int, d_gamma_ptr: int = 0, d_rgb8_ptr: int = 0, stream=0):
+        return self._call(
+            "resolve_device", C.c_void_p(d_sum_ptr), npixels, C.c_void_p(d_gamma_ptr or None), C.c_void_p(d_rgb8_ptr or None), C.c_void_p(stream)
+        )
+
+    def trace_rays(self, origin, direction, time=None, seed=1):
+        o = np.ascontiguousarray(origin, dtype=np.float64)
+        d = np.ascontiguousarray(direction, dtype=np.float64)
+        n = o.shape[0]
+        assert o.shape == (n, 3) and d.shape == (n, 3)
+        t = None
+        if time is not None:
+            t = np.ascontiguousarray(time, dtype=np.float64)
+            assert t.shape == (n,)
+        out = np.zeros(n, dtype=HIT_DTYPE)
+        self._call(
+            "trace_rays", seed, n, _ptr(o, C.c_double), _ptr(d, C.c_double), _ptr(t, C.c_double) if t is not None else None, out.ctypes.data_as(C.c_void_p)
+        )
+        return out
+
+    def camera_rays(self, xyss, seed=1):
+        a = np.ascontiguousarray(xyss, dtype=np.uint32)
+        n = a.shape[0]
+        assert a.shape == (n, 4)
+        out = np.zeros((n, 7), dtype=np.float64)
+        self._call("camera_rays", seed, n, _ptr(a, C.c_uint32), _ptr(out, C.c_double))
+        return out
+
+    def dump_tree(self):
+        """Preorder (kind, creation id, bbox) records of the world tree."""
+        n = self.be.check(self.be.fn("dump_tree")(self.h, None, None, None, 0))
+        kinds = np.zeros(n, dtype=np.int32)
+        ids = np.zeros(n, dtype=np.int32)
+        boxes = np.zeros((n, 6), dtype=np.float64)
+        m = self.be.check(self.be.fn("dump_tree")(self.h, _ptr(kinds, C.c_int32), _ptr(ids, C.c_int32), _ptr(boxes, C.c_double), n))
+        assert m == n
+        return kinds, ids, boxes
+
+
+_gpu_backend = None
+
+
+def load_gpu() -> Backend:
+    """Loads libcaustic_hip.so.  Raises if the library is missing: there is no CPU fallback."""
+    global _gpu_backend
+    if _gpu_backend is None:
+        if not os.path.exists(GPU_LIB_PATH):
+            raise CausticError(f"{GPU_LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` (hipcc, gfx950)")
+        _gpu_backend = Backend(C.CDLL(GPU_LIB_PATH), "chip_", "libcaustic_hip")
+    return _gpu_backend
+
+
+def gpu_device_count() -> int:
+    be = load_gpu()
+    return be.check(be.fn("device_count")())

@@ -1,0 +1,718 @@
+// libcaustic_hip.so: the C ABI of include/caustic_hip.h over the host scene graph
+// (scene_host.hpp) and the gfx950 kernels (kernels.hpp).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "scene_host.hpp"
+
+using namespace chip;
+
+static thread_local std::string g_err;
+static int fail(const std::string& msg) {
+  g_err = msg;
+  return -1;
+}
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t upload(const std::vector<T>& v) {
+    release();
+    n = v.size();
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)&p, bytes);
+    if (e != hipSuccess) return e;
+    if (n) e = hipMemcpy(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+struct chip_scene {
+  HostScene host;
+  bool committed = false;
+  int device = 0;
+  Flat flat;
+  DevBuf<DBvhNode> d_bvh;
+  DevBuf<DSphere> d_spheres;
+  DevBuf<DQuad> d_quads;
+  DevBuf<DGroup> d_groups;
+  DevBuf<nref_t> d_gchild;
+  DevBuf<DTranslate> d_translates;
+  DevBuf<DRotate> d_rotates;
+  DevBuf<DMedium> d_media;
+  DevBuf<nref_t> d_xchain;
+  DevBuf<DMaterial> d_materials;
+  DevBuf<DTexture> d_textures;
+  DevBuf<DPerlin> d_perlins;
+  DevBuf<uint8_t> d_texels;
+  DevBuf<DLight> d_lights;
+  DScene dscene;
+  // path pool
+  bool pool_ready = false;
+  PathPool pool;
+  DevBuf<double> p_ray, p_hit;
+  DevBuf<float> p_st, p_sample;
+  DevBuf<uint32_t> p_hinfo, p_draw, p_qlive0, p_qlive1, p_qmat, p_counters, p_err, p_ovf;
+  DevBuf<unsigned long long> p_stats;
+  uint32_t counters_rows = 0;
+  uint32_t* h_pinned = nullptr;
+
+  void release_device() {
+    d_bvh.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release();
+    d_translates.release(); d_rotates.release(); d_media.release(); d_xchain.release(); d_materials.release();
+    d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
+    p_ray.release(); p_hit.release(); p_st.release(); p_sample.release(); p_hinfo.release(); p_draw.release();
+    p_qlive0.release(); p_qlive1.release(); p_qmat.release(); p_counters.release(); p_err.release(); p_ovf.release();
+    p_stats.release();
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    h_pinned = nullptr;
+    pool_ready = false;
+    committed = false;
+  }
+};
+
+static const uint32_t kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
+
+static size_t pool_capacity_default() {
+  const char* e = getenv("CHIP_POOL_PATHS");
+  if (e && *e) {
+    long long v = atoll(e);
+    if (v >= 4096) return (size_t)v;
+  }
+  return (size_t)1 << 24;
+}
+
+static int ensure_pool(chip_scene* s) {
+  uint32_t rows = s->host.cam.max_depth + 2;
+  if (s->pool_ready && s->counters_rows >= rows) return 0;
+  size_t cap = pool_capacity_default();
+  if (!s->pool_ready) {
+    HIP_TRY(s->p_ray.alloc(7 * cap));
+    HIP_TRY(s->p_hit.alloc(9 * cap));
+    HIP_TRY(s->p_st.alloc(12 * cap));
+    HIP_TRY(s->p_sample.alloc(3 * cap));
+    HIP_TRY(s->p_hinfo.alloc(cap));
+    HIP_TRY(s->p_draw.alloc(cap));
+    HIP_TRY(s->p_qlive0.alloc(cap));
+    HIP_TRY(s->p_qlive1.alloc(cap));
+    HIP_TRY(s->p_qmat.alloc((size_t)MK_COUNT * cap));
+    HIP_TRY(s->p_err.alloc(4));
+    HIP_TRY(s->p_stats.alloc(4));
+    HIP_TRY(s->p_ovf.alloc((size_t)kMaxGridBlocks * CHIP_BLOCK * CHIP_STACK_OVF));
+    HIP_TRY(hipHostMalloc((void**)&s->h_pinned, 64 * sizeof(uint32_t), hipHostMallocDefault));
+  }
+  HIP_TRY(s->p_counters.alloc((size_t)rows * 8));
+  s->counters_rows = rows;
+  PathPool& P = s->pool;
+  P.ray = s->p_ray.p; P.hit = s->p_hit.p; P.st = s->p_st.p; P.sample = s->p_sample.p;
+  P.hinfo = s->p_hinfo.p; P.draw = s->p_draw.p;
+  P.q_live[0] = s->p_qlive0.p; P.q_live[1] = s->p_qlive1.p; P.q_mat = s->p_qmat.p;
+  P.counters = s->p_counters.p; P.errflag = s->p_err.p; P.stats = s->p_stats.p; P.ovf = s->p_ovf.p;
+  P.cap = (uint32_t)cap;
+  s->pool_ready = true;
+  return 0;
+}
+
+static uint32_t grid_for(size_t n) {
+  size_t b = (n + CHIP_BLOCK - 1) / CHIP_BLOCK;
+  if (b < 1) b = 1;
+  if (b > kMaxGridBlocks) b = kMaxGridBlocks;
+  return (uint32_t)b;
+}
+
+struct RenderPlan {
+  uint32_t xmin, xmax, ymin, ymax, rw, rh;
+  std::vector<uint32_t> strata;  // not materialised: first, stride, count
+  uint32_t s_first, s_stride, s_count;
+};
+
+static int plan_render(chip_scene* s, const chip_render_opts* o, RenderPlan& pl) {
+  if (!s->committed) return fail("scene not committed");
+  const DCamera& cam = s->host.cam;
+  pl.xmin = o->xmin; pl.xmax = o->xmax; pl.ymin = o->ymin; pl.ymax = o->ymax;
+  if (pl.xmax == 0 && pl.ymax == 0) { pl.xmin = 0; pl.ymin = 0; pl.xmax = cam.image_width; pl.ymax = cam.image_height; }
+  if (pl.xmax > cam.image_width || pl.ymax > cam.image_height || pl.xmin >= pl.xmax || pl.ymin >= pl.ymax)
+    return fail("render rectangle is empty or outside the image");
+  pl.rw = pl.xmax - pl.xmin;
+  pl.rh = pl.ymax - pl.ymin;
+  uint32_t stride = o->stratum_stride ? o->stratum_stride : 1;
+  if (o->stratum_offset >= stride) return fail("stratum_offset must be < stratum_stride");
+  uint32_t total = cam.sqrt_spp * cam.sqrt_spp;
+  pl.s_first = o->stratum_offset;
+  pl.s_stride = stride;
+  pl.s_count = pl.s_first < total ? (total - pl.s_first + stride - 1) / stride : 0;
+  return 0;
+}
+
+template <uint32_t K>
+static void launch_shade(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, uint32_t grid, hipStream_t st) {
+  hipLaunchKernelGGL(k_shade<K>, dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
+}
+
+// Adds the rectangle's radiance sums for the planned strata into d_sum (device, rw*rh*3 floats).
+static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPlan& pl, float* d_sum, hipStream_t stream, chip_stats* stats) {
+  HIP_TRY(hipSetDevice(s->device));
+  if (ensure_pool(s)) return -1;
+  const PathPool& P = s->pool;
+  const DScene& S = s->dscene;
+  const DCamera& cam = s->host.cam;
+  const bool time_kernels = (o->flags & CHIP_RENDER_TIME_KERNELS) != 0;
+  const bool has_media = !s->flat.media.empty();  // scenes without ConstantMedium run the leaner traversal
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  std::vector<hipEvent_t> kev;  // (begin, end) pairs: even index = trace launch, odd = shade group
+  std::vector<int> kev_kind;
+  auto new_event = [&]() {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    kev.push_back(e);
+    return e;
+  };
+  HIP_TRY(hipMemsetAsync(P.errflag, 0, 4 * sizeof(uint32_t), stream));
+  HIP_TRY(hipMemsetAsync(P.stats, 0, 4 * sizeof(unsigned long long), stream));
+  HIP_TRY(hipEventRecord(ev0, stream));
+  uint64_t n_paths_total = 0, n_trace_launches = 0, n_batches = 0;
+  if (pl.rw > P.cap) return fail("render rectangle is wider than the path pool");
+  uint32_t band_rows = std::min<uint32_t>(pl.rh, P.cap / pl.rw);
+  for (uint32_t by = 0; by < pl.rh; by += band_rows) {
+    uint32_t bh = std::min(band_rows, pl.rh - by);
+    uint32_t npix = pl.rw * bh;
+    uint32_t spb = o->strata_per_batch ? o->strata_per_batch : std::max<uint32_t>(1, P.cap / npix);
+    spb = std::min<uint32_t>(spb, std::max<uint32_t>(1, P.cap / npix));
+    for (uint32_t sb0 = 0; sb0 < pl.s_count; sb0 += spb) {
+      BatchDesc B;
+      B.rect_x0 = pl.xmin; B.rect_y0 = pl.ymin + by; B.rect_w = pl.rw; B.rect_h = bh;
+      B.npix = npix;
+      B.n_strata = std::min(spb, pl.s_count - sb0);
+      B.stratum_first = pl.s_first + sb0 * pl.s_stride;
+      B.stratum_stride = pl.s_stride;
+      B.n_paths = npix * B.n_strata;
+      B.seed_lo = (uint32_t)o->seed;
+      B.seed_hi = (uint32_t)(o->seed >> 32);
+      n_paths_total += B.n_paths;
+      n_batches++;
+      HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)s->counters_rows * 8 * sizeof(uint32_t), stream));
+      hipLaunchKernelGGL(k_raygen, dim3(grid_for(B.n_paths)), dim3(CHIP_BLOCK), 0, stream, S, P, B);
+      uint32_t live_upper = B.n_paths;
+      for (uint32_t bounce = 0; bounce < cam.max_depth; bounce++) {
+        uint32_t grid = grid_for(live_upper);
+        if (time_kernels) (void)hipEventRecord(new_event(), stream);
+        if (has_media) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce);
+        else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce);
+        if (time_kernels) (void)hipEventRecord(new_event(), stream);
+        n_trace_launches++;
+        launch_shade<MK_LAMBERTIAN>(S, P, B, bounce, grid, stream);
+        launch_shade<MK_METAL>(S, P, B, bounce, grid, stream);
+        launch_shade<MK_DIELECTRIC>(S, P, B, bounce, grid, stream);
+        launch_shade<MK_DIFFUSE_LIGHT>(S, P, B, bounce, grid, stream);
+        launch_shade<MK_ISOTROPIC>(S, P, B, bounce, grid, stream);
+        launch_shade<MK_EMPTY>(S, P, B, bounce, grid, stream);
+        if (time_kernels) (void)hipEventRecord(new_event(), stream);
+        // every few bounces learn how many paths are still alive (stops the loop early)
+        if (bounce + 1 < cam.max_depth && (bounce % 4) == 3) {
+          HIP_TRY(hipMemcpyAsync(s->h_pinned, P.counters + (size_t)(bounce + 1) * 8, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+          HIP_TRY(hipStreamSynchronize(stream));
+          live_upper = s->h_pinned[0];
+          if (live_upper == 0) break;
+        }
+      }
+      hipLaunchKernelGGL(k_accumulate, dim3(grid_for(npix)), dim3(CHIP_BLOCK), 0, stream, P, B, d_sum + (size_t)by * pl.rw * 3);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  HIP_TRY(hipEventRecord(ev1, stream));
+  HIP_TRY(hipMemcpyAsync(s->h_pinned + 8, P.errflag, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(s->h_pinned + 16, P.stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(hipGetLastError());
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+  double ms_trace = 0.0, ms_shade = 0.0;
+  for (size_t i = 0; i + 2 < kev.size(); i += 3) {  // (trace begin, trace end = shade begin, shade end) per bounce
+    float a = 0.f, b = 0.f;
+    (void)hipEventElapsedTime(&a, kev[i], kev[i + 1]);
+    (void)hipEventElapsedTime(&b, kev[i + 1], kev[i + 2]);
+    ms_trace += a;
+    ms_shade += b;
+  }
+  for (hipEvent_t e : kev) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  if (s->h_pinned[8] & 1u) return fail("traversal stack overflow (scene nesting deeper than the device stack)");
+  if (stats) {
+    const unsigned long long* st = (const unsigned long long*)(s->h_pinned + 16);
+    stats->paths = n_paths_total;
+    stats->segments = st[0];
+    stats->bvh_visits = st[1];
+    stats->prim_tests = st[2];
+    stats->ms_total = ms;
+    stats->ms_trace = ms_trace;
+    stats->ms_shade = ms_shade;
+    stats->ms_other = 0.0;
+    stats->trace_launches = n_trace_launches;
+    stats->batches = n_batches;
+  }
+  return 0;
+}
+
+extern "C" {
+
+const char* chip_last_error(void) { return g_err.c_str(); }
+
+int chip_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  return n;
+}
+
+chip_scene* chip_scene_create(void) { return new chip_scene(); }
+void chip_scene_destroy(chip_scene* s) {
+  if (!s) return;
+  s->release_device();
+  delete s;
+}
+
+#define NEED_SCENE if (!s) return fail("null scene")
+#define CHECK_TEX(id) if ((id) < 0 || (size_t)(id) >= s->host.textures.size()) return fail("bad texture id")
+#define CHECK_MAT(id) if ((id) < 0 || (size_t)(id) >= s->host.materials.size()) return fail("bad material id")
+#define CHECK_NODE(id) if ((id) < 0 || (size_t)(id) >= s->host.handle.size()) return fail("bad node id")
+
+static int add_tex(chip_scene* s, const DTexture& t) {
+  s->host.textures.push_back(t);
+  s->committed = false;
+  return (int)s->host.textures.size() - 1;
+}
+static int add_mat(chip_scene* s, uint32_t kind, int tex, double p0, double p1, double p2, double p3) {
+  DMaterial m;
+  m.kind = kind;
+  m.tex = tex;
+  m.p[0] = p0; m.p[1] = p1; m.p[2] = p2; m.p[3] = p3;
+  s->host.materials.push_back(m);
+  s->committed = false;
+  return (int)s->host.materials.size() - 1;
+}
+static DTexture solid_tex(double r, double g, double b) {
+  DTexture t;
+  memset(&t, 0, sizeof(t));
+  t.kind = TK_SOLID;
+  t.p[0] = r; t.p[1] = g; t.p[2] = b;
+  return t;
+}
+
+int chip_tex_solid(chip_scene* s, double r, double g, double b) {
+  NEED_SCENE;
+  return add_tex(s, solid_tex(r, g, b));
+}
+int chip_tex_checker(chip_scene* s, double scale, int even, int odd) {
+  NEED_SCENE;
+  CHECK_TEX(even);
+  CHECK_TEX(odd);
+  DTexture t;
+  memset(&t, 0, sizeof(t));
+  t.kind = TK_CHECKER;
+  t.a = (uint32_t)even;
+  t.b = (uint32_t)odd;
+  t.p[0] = 1.0 / scale;  // checker_texture.rs:15
+  return add_tex(s, t);
+}
+int chip_tex_image(chip_scene* s, uint32_t w, uint32_t h, const uint8_t* rgb) {
+  NEED_SCENE;
+  if (!rgb || w == 0 || h == 0) return fail("bad image");
+  DTexture t;
+  memset(&t, 0, sizeof(t));
+  t.kind = TK_IMAGE;
+  t.a = w;
+  t.b = h;
+  t.c = (uint32_t)s->host.texels.size();
+  s->host.texels.insert(s->host.texels.end(), rgb, rgb + (size_t)w * h * 3);
+  return add_tex(s, t);
+}
+static int add_perlin(chip_scene* s, const double* rand_vec, const int32_t* px, const int32_t* py, const int32_t* pz) {
+  DPerlin p;
+  memcpy(p.rand_vec, rand_vec, sizeof(p.rand_vec));
+  for (int i = 0; i < 256; i++) {
+    if ((uint32_t)px[i] > 255 || (uint32_t)py[i] > 255 || (uint32_t)pz[i] > 255) return fail("perlin permutation entry out of range");
+    p.perm_x[i] = px[i]; p.perm_y[i] = py[i]; p.perm_z[i] = pz[i];
+  }
+  s->host.perlins.push_back(p);
+  return (int)s->host.perlins.size() - 1;
+}
+int chip_tex_perlin_noise(chip_scene* s, double scale, const double* rand_vec, const int32_t* px, const int32_t* py, const int32_t* pz) {
+  NEED_SCENE;
+  if (!rand_vec || !px || !py || !pz) return fail("null perlin table");
+  int pi = add_perlin(s, rand_vec, px, py, pz);
+  if (pi < 0) return -1;
+  DTexture t;
+  memset(&t, 0, sizeof(t));
+  t.kind = TK_NOISE;
+  t.a = (uint32_t)pi;
+  t.p[0] = scale;
+  return add_tex(s, t);
+}
+int chip_tex_perlin_turbulence(chip_scene* s, double scale, uint32_t depth, const double* rand_vec, const int32_t* px, const int32_t* py,
+                               const int32_t* pz) {
+  NEED_SCENE;
+  if (!rand_vec || !px || !py || !pz) return fail("null perlin table");
+  int pi = add_perlin(s, rand_vec, px, py, pz);
+  if (pi < 0) return -1;
+  DTexture t;
+  memset(&t, 0, sizeof(t));
+  t.kind = TK_TURBULENCE;
+  t.a = (uint32_t)pi;
+  t.b = depth;
+  t.p[0] = scale;
+  return add_tex(s, t);
+}
+
+int chip_lambertian_color(chip_scene* s, double r, double g, double b) {
+  NEED_SCENE;
+  int t = add_tex(s, solid_tex(r, g, b));
+  return add_mat(s, MK_LAMBERTIAN, t, 0, 0, 0, 0);
+}
+int chip_lambertian_tex(chip_scene* s, int tex) {
+  NEED_SCENE;
+  CHECK_TEX(tex);
+  return add_mat(s, MK_LAMBERTIAN, tex, 0, 0, 0, 0);
+}
+int chip_metal(chip_scene* s, double r, double g, double b, double fuzz) {
+  NEED_SCENE;
+  return add_mat(s, MK_METAL, -1, r, g, b, fuzz);
+}
+int chip_dielectric(chip_scene* s, double ri) {
+  NEED_SCENE;
+  return add_mat(s, MK_DIELECTRIC, -1, ri, 0, 0, 0);
+}
+int chip_diffuse_light_color(chip_scene* s, double r, double g, double b) {
+  NEED_SCENE;
+  int t = add_tex(s, solid_tex(r, g, b));
+  return add_mat(s, MK_DIFFUSE_LIGHT, t, 0, 0, 0, 0);
+}
+int chip_diffuse_light_tex(chip_scene* s, int tex) {
+  NEED_SCENE;
+  CHECK_TEX(tex);
+  return add_mat(s, MK_DIFFUSE_LIGHT, tex, 0, 0, 0, 0);
+}
+int chip_empty_material(chip_scene* s) {
+  NEED_SCENE;
+  return add_mat(s, MK_EMPTY, -1, 0, 0, 0, 0);
+}
+
+int chip_sphere(chip_scene* s, const double* c, double r, int mat) {
+  NEED_SCENE;
+  CHECK_MAT(mat);
+  s->committed = false;
+  return s->host.nodes[s->host.make_sphere(c, r, mat, true)].id;
+}
+int chip_sphere_set_direction(chip_scene* s, int node, const double* d) {
+  NEED_SCENE;
+  CHECK_NODE(node);
+  int h = s->host.handle[node];
+  if (s->host.nodes[h].kind != CHIP_NODE_SPHERE) return fail("node is not a sphere");
+  if (s->host.nodes[h].referenced) return fail("sphere already referenced");
+  s->host.sphere_set_direction(h, d);
+  s->committed = false;
+  return 0;
+}
+int chip_quad(chip_scene* s, const double* q, const double* u, const double* v, int mat) {
+  NEED_SCENE;
+  CHECK_MAT(mat);
+  s->committed = false;
+  return s->host.nodes[s->host.make_quad(q, u, v, mat, true)].id;
+}
+int chip_box(chip_scene* s, const double* a, const double* b, int mat) {
+  NEED_SCENE;
+  CHECK_MAT(mat);
+  s->committed = false;
+  return s->host.nodes[s->host.make_box(a, b, mat)].id;
+}
+static int to_host_ids(chip_scene* s, const int32_t* ids, int n, std::vector<int>& out) {
+  if (n < 0 || (n > 0 && !ids)) return fail("bad node list");
+  out.resize(n);
+  for (int i = 0; i < n; i++) {
+    CHECK_NODE(ids[i]);
+    out[i] = s->host.handle[ids[i]];
+  }
+  return 0;
+}
+int chip_group(chip_scene* s, const int32_t* ids, int n) {
+  NEED_SCENE;
+  std::vector<int> v;
+  if (to_host_ids(s, ids, n, v)) return -1;
+  s->committed = false;
+  return s->host.nodes[s->host.make_group(v, CHIP_NODE_GROUP, true)].id;
+}
+int chip_bvh(chip_scene* s, const int32_t* ids, int n) {
+  NEED_SCENE;
+  std::vector<int> v;
+  if (to_host_ids(s, ids, n, v)) return -1;
+  s->committed = false;
+  return s->host.nodes[s->host.make_bvh(v, true)].id;
+}
+int chip_translate(chip_scene* s, int node, const double* off) {
+  NEED_SCENE;
+  CHECK_NODE(node);
+  s->committed = false;
+  return s->host.nodes[s->host.make_translate(s->host.handle[node], off)].id;
+}
+int chip_rotate(chip_scene* s, int node, const double* axis, double deg) {
+  NEED_SCENE;
+  CHECK_NODE(node);
+  s->committed = false;
+  return s->host.nodes[s->host.make_rotate(s->host.handle[node], axis, deg)].id;
+}
+int chip_constant_medium_color(chip_scene* s, int boundary, double density, double r, double g, double b) {
+  NEED_SCENE;
+  CHECK_NODE(boundary);
+  int t = add_tex(s, solid_tex(r, g, b));
+  int m = add_mat(s, MK_ISOTROPIC, t, 0, 0, 0, 0);  // isotropic.rs:21-25
+  return s->host.nodes[s->host.make_medium(s->host.handle[boundary], density, m)].id;
+}
+int chip_constant_medium_tex(chip_scene* s, int boundary, double density, int tex) {
+  NEED_SCENE;
+  CHECK_NODE(boundary);
+  CHECK_TEX(tex);
+  int m = add_mat(s, MK_ISOTROPIC, tex, 0, 0, 0, 0);  // isotropic.rs:17-19
+  return s->host.nodes[s->host.make_medium(s->host.handle[boundary], density, m)].id;
+}
+
+int chip_scene_set_world(chip_scene* s, int node) {
+  NEED_SCENE;
+  CHECK_NODE(node);
+  s->host.world = node;
+  s->committed = false;
+  return 0;
+}
+int chip_scene_set_lights(chip_scene* s, int node) {
+  NEED_SCENE;
+  if (node >= 0) CHECK_NODE(node);
+  s->host.lights = node < 0 ? -1 : node;
+  s->committed = false;
+  return 0;
+}
+int chip_scene_set_camera(chip_scene* s, const chip_camera_desc* d) {
+  NEED_SCENE;
+  if (!d) return fail("null camera desc");
+  if (d->image_width == 0) return fail("image_width must be > 0");
+  if (d->samples_per_pixel == 0) return fail("samples_per_pixel must be > 0");
+  s->host.build_camera(*d);
+  s->committed = false;
+  return 0;
+}
+
+int chip_commit(chip_scene* s) {
+  NEED_SCENE;
+  Flat F;
+  try {
+    s->host.flatten(F);
+  } catch (const std::exception& e) {
+    return fail(e.what());
+  }
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  s->device = dev;
+  HIP_TRY(s->d_bvh.upload(F.bvh));
+  HIP_TRY(s->d_spheres.upload(F.spheres));
+  HIP_TRY(s->d_quads.upload(F.quads));
+  HIP_TRY(s->d_groups.upload(F.groups));
+  HIP_TRY(s->d_gchild.upload(F.gchild));
+  HIP_TRY(s->d_translates.upload(F.translates));
+  HIP_TRY(s->d_rotates.upload(F.rotates));
+  HIP_TRY(s->d_media.upload(F.media));
+  HIP_TRY(s->d_xchain.upload(F.xchain));
+  HIP_TRY(s->d_materials.upload(s->host.materials));
+  HIP_TRY(s->d_textures.upload(s->host.textures));
+  HIP_TRY(s->d_perlins.upload(s->host.perlins));
+  HIP_TRY(s->d_texels.upload(s->host.texels));
+  if (F.has_lights && F.lights.empty() && !F.lights_is_group) return fail("internal: empty light list");
+  HIP_TRY(s->d_lights.upload(F.lights));
+  DScene& D = s->dscene;
+  D.bvh = s->d_bvh.p; D.spheres = s->d_spheres.p; D.quads = s->d_quads.p; D.groups = s->d_groups.p; D.gchild = s->d_gchild.p;
+  D.translates = s->d_translates.p; D.rotates = s->d_rotates.p; D.media = s->d_media.p; D.xchain = s->d_xchain.p;
+  D.materials = s->d_materials.p; D.textures = s->d_textures.p; D.perlins = s->d_perlins.p; D.texels = s->d_texels.p;
+  D.lights = s->d_lights.p;
+  D.root = F.root;
+  D.n_lights = (uint32_t)F.lights.size();
+  D.has_lights = F.has_lights;
+  D.lights_is_group = F.lights_is_group;
+  D.cam = s->host.cam;
+  s->flat = std::move(F);
+  s->committed = true;
+  return 0;
+}
+
+int chip_image_size(chip_scene* s, uint32_t* w, uint32_t* h) {
+  NEED_SCENE;
+  if (!s->host.has_camera) return fail("scene has no camera");
+  if (w) *w = s->host.cam.image_width;
+  if (h) *h = s->host.cam.image_height;
+  return 0;
+}
+int chip_sqrt_spp(chip_scene* s) {
+  NEED_SCENE;
+  if (!s->host.has_camera) return fail("scene has no camera");
+  return (int)s->host.cam.sqrt_spp;
+}
+int chip_camera_derived(chip_scene* s, double* out) {
+  NEED_SCENE;
+  if (!s->host.has_camera) return fail("scene has no camera");
+  const DCamera& c = s->host.cam;
+  const double* vs[6] = {c.center, c.pixel00, c.du, c.dv, c.disk_u, c.disk_v};
+  for (int i = 0; i < 6; i++)
+    for (int k = 0; k < 3; k++) out[3 * i + k] = vs[i][k];
+  out[18] = c.pixel_samples_scale;
+  out[19] = c.recip_sqrt_spp;
+  out[20] = c.defocus_angle;
+  out[21] = c.sqrt_spp;
+  out[22] = c.image_width;
+  out[23] = c.image_height;
+  return 0;
+}
+
+int chip_render_accumulate_device(chip_scene* s, const chip_render_opts* opts, float* d_sum_rgb, void* stream, chip_stats* stats) {
+  NEED_SCENE;
+  if (!opts || !d_sum_rgb) return fail("null argument");
+  RenderPlan pl;
+  if (plan_render(s, opts, pl)) return -1;
+  return render_into(s, opts, pl, d_sum_rgb, (hipStream_t)stream, stats);
+}
+
+int chip_resolve_device(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, void* stream) {
+  NEED_SCENE;
+  if (!s->host.has_camera) return fail("scene has no camera");
+  if (!d_sum_rgb) return fail("null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  hipLaunchKernelGGL(k_resolve, dim3(grid_for(npixels * 3)), dim3(CHIP_BLOCK), 0, (hipStream_t)stream, d_sum_rgb, npixels * 3,
+                     s->host.cam.pixel_samples_scale, d_out_gamma, d_out_rgb8);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int chip_render_frame(chip_scene* s, const chip_render_opts* opts, float* out_sum_rgb, uint8_t* out_rgb8, chip_stats* stats) {
+  NEED_SCENE;
+  if (!opts) return fail("null argument");
+  RenderPlan pl;
+  if (plan_render(s, opts, pl)) return -1;
+  HIP_TRY(hipSetDevice(s->device));
+  size_t npix = (size_t)pl.rw * pl.rh;
+  DevBuf<float> d_sum;
+  DevBuf<uint8_t> d_rgb8;
+  HIP_TRY(d_sum.alloc(npix * 3));
+  HIP_TRY(hipMemset(d_sum.p, 0, npix * 3 * sizeof(float)));
+  int rc = render_into(s, opts, pl, d_sum.p, nullptr, stats);
+  if (rc == 0 && out_sum_rgb) {
+    hipError_t e = hipMemcpy(out_sum_rgb, d_sum.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(std::string("hipMemcpy: ") + hipGetErrorString(e));
+  }
+  if (rc == 0 && out_rgb8) {
+    hipError_t e = d_rgb8.alloc(npix * 3);
+    if (e == hipSuccess) {
+      rc = chip_resolve_device(s, d_sum.p, npix, nullptr, d_rgb8.p, nullptr);
+      if (rc == 0) e = hipMemcpy(out_rgb8, d_rgb8.p, npix * 3, hipMemcpyDeviceToHost);
+    }
+    if (e != hipSuccess) rc = fail(std::string("rgb8 output: ") + hipGetErrorString(e));
+  }
+  d_sum.release();
+  d_rgb8.release();
+  return rc;
+}
+
+int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, const double* d, const double* tm, chip_hit* out) {
+  NEED_SCENE;
+  if (!s->committed) return fail("scene not committed");
+  if (n == 0) return 0;
+  if (!o || !d || !out) return fail("null argument");
+  if (n > 0xFFFFFFFFull) return fail("too many rays");
+  static_assert(sizeof(chip_hit) == sizeof(DHitOut), "hit layout");
+  HIP_TRY(hipSetDevice(s->device));
+  if (ensure_pool(s)) return -1;
+  DevBuf<double> d_o, d_d, d_t;
+  DevBuf<DHitOut> d_out;
+  int rc = 0;
+  hipError_t e;
+  do {
+    if ((e = d_o.alloc(3 * n)) != hipSuccess) break;
+    if ((e = d_d.alloc(3 * n)) != hipSuccess) break;
+    if ((e = d_out.alloc(n)) != hipSuccess) break;
+    if ((e = hipMemcpy(d_o.p, o, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
+    if ((e = hipMemcpy(d_d.p, d, 3 * n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
+    if (tm) {
+      if ((e = d_t.alloc(n)) != hipSuccess) break;
+      if ((e = hipMemcpy(d_t.p, tm, n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
+    }
+    if ((e = hipMemset(s->pool.errflag, 0, 4 * sizeof(uint32_t))) != hipSuccess) break;
+    if (!s->flat.media.empty())
+      hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, s->dscene, s->pool, (uint32_t)seed,
+                         (uint32_t)(seed >> 32), (uint32_t)n, d_o.p, d_d.p, tm ? d_t.p : nullptr, d_out.p);
+    else
+      hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, s->dscene, s->pool, (uint32_t)seed,
+                         (uint32_t)(seed >> 32), (uint32_t)n, d_o.p, d_d.p, tm ? d_t.p : nullptr, d_out.p);
+    if ((e = hipGetLastError()) != hipSuccess) break;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+    if ((e = hipMemcpy(out, d_out.p, n * sizeof(DHitOut), hipMemcpyDeviceToHost)) != hipSuccess) break;
+    uint32_t err[4];
+    if ((e = hipMemcpy(err, s->pool.errflag, sizeof(err), hipMemcpyDeviceToHost)) != hipSuccess) break;
+    if (err[0] & 1u) rc = fail("traversal stack overflow (scene nesting deeper than the device stack)");
+  } while (0);
+  d_o.release(); d_d.release(); d_t.release(); d_out.release();
+  if (e != hipSuccess) return fail(std::string("chip_trace_rays: ") + hipGetErrorString(e));
+  return rc;
+}
+
+int chip_camera_rays(chip_scene* s, uint64_t seed, size_t n, const uint32_t* xyss, double* rays) {
+  NEED_SCENE;
+  if (!s->committed) return fail("scene not committed");
+  if (n == 0) return 0;
+  if (!xyss || !rays) return fail("null argument");
+  if (n > 0xFFFFFFFFull) return fail("too many rays");
+  HIP_TRY(hipSetDevice(s->device));
+  DevBuf<uint32_t> d_in;
+  DevBuf<double> d_out;
+  hipError_t e;
+  do {
+    if ((e = d_in.alloc(4 * n)) != hipSuccess) break;
+    if ((e = d_out.alloc(7 * n)) != hipSuccess) break;
+    if ((e = hipMemcpy(d_in.p, xyss, 4 * n * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) break;
+    hipLaunchKernelGGL(k_camera_rays, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, s->dscene, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       (uint32_t)n, d_in.p, d_out.p);
+    if ((e = hipGetLastError()) != hipSuccess) break;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+    e = hipMemcpy(rays, d_out.p, 7 * n * sizeof(double), hipMemcpyDeviceToHost);
+  } while (0);
+  d_in.release(); d_out.release();
+  if (e != hipSuccess) return fail(std::string("chip_camera_rays: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int64_t chip_dump_tree(chip_scene* s, int32_t* kinds, int32_t* ids, double* boxes, size_t cap) {
+  NEED_SCENE;
+  if (s->host.world < 0) return fail("scene has no world");
+  size_t count = 0;
+  s->host.dump(s->host.handle[s->host.world], kinds, ids, boxes, cap, count);
+  return (int64_t)count;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// Flattened scene records shared by the host flattener and the gfx950 kernels.
+// All geometry is f64 (the reference computes in f64 and hit/miss decisions must
+// agree with it); radiance state and the framebuffer are f32.
+#pragma once
+#include <stdint.h>
+
+// A node reference: kind in the top 4 bits, index into that kind's table below.
+typedef uint32_t nref_t;
+enum : uint32_t {
+  NK_BVH = 0,
+  NK_SPHERE = 1,
+  NK_QUAD = 2,
+  NK_GROUP = 3,
+  NK_TRANSLATE = 4,
+  NK_ROTATE = 5,
+  NK_MEDIUM = 6,
+  NK_EXIT_TRANSLATE = 7,  // traversal-stack marker: leave a Translate
+  NK_EXIT_ROTATE = 8,     // traversal-stack marker: leave a Rotate
+  NK_GROUP_CONT = 9,      // traversal-stack marker: continue a Group at the child index stored below it
+  NK_NONE = 15,
+};
+#define NREF(kind, idx) ((nref_t)(((uint32_t)(kind) << 28) | (uint32_t)(idx)))
+#define NREF_KIND(r) ((r) >> 28)
+#define NREF_INDEX(r) ((r)&0x0FFFFFFFu)
+#define NREF_NONE NREF(NK_NONE, 0x0FFFFFFF)
+
+// One BVH node: its own box (tested on entry, as bounding_volume_hierarchy.rs:59 does)
+// and its two children in reference order (left is always visited first).
+struct alignas(64) DBvhNode {
+  double box[6];  // xmin,xmax,ymin,ymax,zmin,zmax
+  nref_t left, right;
+  uint32_t pad[2];
+};
+
+struct alignas(16) DSphere {
+  double c[3];   // center at time 0
+  double dc[3];  // center motion per unit time
+  double r;
+  uint32_t mat;
+  nref_t xform;  // innermost Translate/Rotate ancestor, or NREF_NONE
+  int32_t leaf_id;
+  uint32_t pad;
+};
+
+struct alignas(16) DQuad {
+  double q[3], u[3], v[3], n[3], w[3];
+  double d, area;
+  uint32_t mat;
+  nref_t xform;
+  int32_t leaf_id;
+  uint32_t pad;
+};
+
+struct DGroup {
+  uint32_t first, count;  // children are gchild[first .. first+count)
+};
+
+struct alignas(8) DTranslate {
+  double off[3];
+  nref_t child;
+  nref_t parent_xform;             // innermost transform ancestor of this node, or NREF_NONE
+  uint32_t chain_first, chain_len;  // this node's root->self transform chain in xchain[]
+};
+
+struct alignas(8) DRotate {
+  double m[9];  // row-major rotation; the inverse is its transpose (rotate.rs:52-68)
+  nref_t child;
+  nref_t parent_xform;
+  uint32_t chain_first, chain_len;
+};
+
+struct alignas(8) DMedium {
+  double neg_inv_density;
+  nref_t boundary;
+  uint32_t mat;  // Isotropic material
+  nref_t xform;
+  int32_t leaf_id;
+};
+
+enum : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_DIFFUSE_LIGHT = 3, MK_ISOTROPIC = 4, MK_EMPTY = 5, MK_COUNT = 6 };
+struct alignas(8) DMaterial {
+  uint32_t kind;
+  int32_t tex;  // Lambertian / DiffuseLight / Isotropic texture id
+  double p[4];  // Metal: albedo rgb, fuzz; Dielectric: refraction index
+};
+
+enum : uint32_t { TK_SOLID = 0, TK_CHECKER = 1, TK_IMAGE = 2, TK_NOISE = 3, TK_TURBULENCE = 4 };
+struct alignas(8) DTexture {
+  uint32_t kind;
+  uint32_t a, b;  // checker: even, odd texture ids; image: width, height; perlin: table index, turbulence depth
+  uint32_t c;     // image: byte offset into texels
+  double p[3];    // solid: rgb; checker: inv_scale; perlin: scale
+};
+
+struct DPerlin {
+  double rand_vec[256 * 3];
+  int32_t perm_x[256], perm_y[256], perm_z[256];
+};
+
+enum : uint32_t { LK_SPHERE = 1, LK_QUAD = 2, LK_OTHER = 0 };
+struct DLight {
+  uint32_t kind;
+  uint32_t index;  // into spheres / quads
+};
+
+struct DCamera {  // Camera, camera.rs:202-231
+  double center[3], pixel00[3], du[3], dv[3], disk_u[3], disk_v[3];
+  double background[3];
+  double pixel_samples_scale, recip_sqrt_spp, defocus_angle;
+  uint32_t image_width, image_height, max_depth, sqrt_spp;
+};
+
+struct DScene {
+  const DBvhNode* bvh;
+  const DSphere* spheres;
+  const DQuad* quads;
+  const DGroup* groups;
+  const nref_t* gchild;
+  const DTranslate* translates;
+  const DRotate* rotates;
+  const DMedium* media;
+  const nref_t* xchain;
+  const DMaterial* materials;
+  const DTexture* textures;
+  const DPerlin* perlins;
+  const uint8_t* texels;
+  const DLight* lights;
+  nref_t root;
+  uint32_t n_lights;
+  uint32_t has_lights;       // SceneData.lights is Some
+  uint32_t lights_is_group;  // lights root is a Group (one member is picked per sample)
+  DCamera cam;
+};

@@ -1,0 +1,964 @@
+// gfx950 kernels of the wavefront path tracer: ray generation, closest-hit
+// traversal, material-binned shading with cosine / light / mixture importance
+// sampling, per-pixel accumulation and the final resolve.
+//
+// Geometry runs in f64 with the reference's expression order (build with
+// -ffp-contract=off), so box / sphere / quad decisions are the same as
+// crates/core's for the same ray.  Citations give the reference file:line a
+// device function restates (paths relative to crates/core/src/).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_scene.h"
+
+#define CHIP_BLOCK 256
+#define CHIP_STACK_LDS 24  // per-lane short stack entries kept in LDS
+#define CHIP_STACK_OVF 40  // further entries spill to a per-thread global slab
+#define CHIP_PI 3.14159265358979323846
+#define CHIP_BIG 1e30f
+
+// ------------------------------------------------------------------ path pool (SoA, stride = capacity)
+struct PathPool {
+  double* ray;      // [7][cap]  origin xyz, direction xyz, time
+  double* hit;      // [9][cap]  t, pt xyz, normal xyz, u, v
+  float* st;        // [12][cap] a rgb, b rgb, lo rgb, hi rgb of  x -> clamp(a + b x, lo, hi)
+  uint32_t* hinfo;  // [cap]     material id | front_face << 31
+  uint32_t* draw;   // [cap]     uniforms already consumed in the current bounce
+  float* sample;    // [3][cap]  finished sample radiance
+  uint32_t* q_live[2];  // [cap] live path slots, ping-pong per bounce
+  uint32_t* q_mat;      // [MK_COUNT][cap] per-material-kind shade queues
+  uint32_t* counters;   // [max_depth+1][8]: [b][0] live entering bounce b, [b][1..6] material queue sizes
+  uint32_t* errflag;    // [4]: [0] traversal stack overflow
+  unsigned long long* stats;  // [4]: segments, bvh visits, prim tests, spare
+  uint32_t* ovf;        // [threads][CHIP_STACK_OVF] traversal stack spill
+  uint32_t cap;
+};
+
+struct BatchDesc {
+  uint32_t rect_x0, rect_y0, rect_w, rect_h;  // pixel rectangle
+  uint32_t npix;                              // rect_w * rect_h
+  uint32_t n_strata;                          // strata in this batch
+  uint32_t stratum_first, stratum_stride;     // global stratum of batch-local sb: first + sb*stride
+  uint32_t n_paths;                           // npix * n_strata
+  uint32_t seed_lo, seed_hi;
+};
+
+// ------------------------------------------------------------------ Philox4x32-10 stream
+// Counter (pixel, stratum, bounce, block), key = seed; each block yields two
+// 53-bit uniforms in [0,1).  Replaces RenderContext.random (lib.rs:34-36).
+struct Rng {
+  uint32_t k0, k1, pixel, stratum, bounce, draw;
+  uint32_t cached_block;
+  uint32_t c[4];
+  __device__ void init(uint32_t seed_lo, uint32_t seed_hi, uint32_t px, uint32_t st, uint32_t b, uint32_t d) {
+    k0 = seed_lo; k1 = seed_hi; pixel = px; stratum = st; bounce = b; draw = d;
+    cached_block = 0xFFFFFFFFu;
+  }
+  __device__ void block(uint32_t blk) {
+    uint32_t c0 = pixel, c1 = stratum, c2 = bounce, c3 = blk, a = k0, b = k1;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+      uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+      uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      uint32_t n0 = hi1 ^ c1 ^ a, n2 = hi0 ^ c3 ^ b;
+      c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+      a += 0x9E3779B9u;
+      b += 0xBB67AE85u;
+    }
+    c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
+    cached_block = blk;
+  }
+  __device__ double next() {
+    uint32_t blk = draw >> 1;
+    if (blk != cached_block) block(blk);
+    uint32_t lo = (draw & 1) ? c[2] : c[0], hi = (draw & 1) ? c[3] : c[1];
+    draw++;
+    unsigned long long u = (((unsigned long long)hi << 32) | lo) >> 11;
+    return (double)u * (1.0 / 9007199254740992.0);
+  }
+  // random.rs:169-176 forms
+  __device__ double interval(double mn, double mx) { return mn + (mx - mn) * next(); }
+};
+#define CHIP_CAMERA_BOUNCE 0xFFFFFFFFu
+#define CHIP_REJECT_CAP 64  // bound on rejection-sampling loops (P(miss) < 1e-20)
+
+// ------------------------------------------------------------------ small f64 vector helpers (vector.rs)
+struct V3 {
+  double x, y, z;
+};
+__device__ inline V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+__device__ inline V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ inline V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ inline V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+__device__ inline V3 operator*(V3 a, double s) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ inline V3 operator*(double s, V3 a) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ inline V3 operator/(V3 a, double s) { return V3{a.x / s, a.y / s, a.z / s}; }
+__device__ inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vector.rs:211-213
+__device__ inline V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ inline double len2(V3 a) {  // vector.rs:188-193
+  double xs = a.x * a.x, ys = a.y * a.y, zs = a.z * a.z;
+  return xs + ys + zs;
+}
+__device__ inline double len(V3 a) { return sqrt(len2(a)); }
+__device__ inline V3 unit(V3 a) { return a / len(a); }
+__device__ inline V3 ld3(const double* p) { return V3{p[0], p[1], p[2]}; }
+__device__ inline V3 reflect(V3 v, V3 n) { return v - 2.0 * dot(v, n) * n; }  // vector.rs:294-296
+__device__ inline V3 refract(V3 uv, V3 n, double eta) {                      // vector.rs:304-309
+  double cos_theta = fmin(dot(-uv, n), 1.0);
+  V3 perp = eta * (uv + cos_theta * n);
+  V3 par = -sqrt(fabs(1.0 - len2(perp))) * n;
+  return perp + par;
+}
+// matrix.rs:91-97 with row-major m; mulT multiplies by the transpose (rotate.rs:52-68)
+__device__ inline V3 mat_mul(const double* m, V3 v) {
+  return V3{m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+__device__ inline V3 mat_mulT(const double* m, V3 v) {
+  return V3{m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z};
+}
+__device__ inline V3 random_unit(Rng& r) {  // vector.rs:79-87
+  V3 p = mk(1, 0, 0);
+  for (int it = 0; it < CHIP_REJECT_CAP; it++) {
+    double x = r.interval(-1.0, 1.0);
+    double y = r.interval(-1.0, 1.0);
+    double z = r.interval(-1.0, 1.0);
+    p = mk(x, y, z);
+    double l2 = len2(p);
+    if (1e-160 < l2 && l2 <= 1.0) return p / sqrt(l2);
+  }
+  return unit(p);
+}
+__device__ inline V3 random_cosine_direction(Rng& r) {  // vector.rs:136-146
+  double r1 = r.next();
+  double r2 = r.next();
+  double phi = 2.0 * CHIP_PI * r1;
+  double x = cos(phi) * sqrt(r2);
+  double y = sin(phi) * sqrt(r2);
+  double z = sqrt(1.0 - r2);
+  return mk(x, y, z);
+}
+struct Onb {  // utils/orthonormal_basis.rs:57-68,95-97
+  V3 u, v, w;
+  __device__ explicit Onb(V3 normal) {
+    w = unit(normal);
+    V3 a = fabs(w.x) > 0.9 ? mk(0.0, 1.0, 0.0) : mk(1.0, 0.0, 0.0);
+    v = unit(cross(w, a));
+    u = cross(w, v);
+  }
+  __device__ V3 local(V3 p) const { return (p.x * u) + (p.y * v) + (p.z * w); }
+};
+
+// ------------------------------------------------------------------ traversal
+struct TravRay {
+  V3 wo, wd;        // world-space ray (camera.rs:264 passes it to world.hit)
+  V3 o, d, inv;     // ray in the current node's space and 1/d (aabb.rs:202)
+  double time;
+};
+struct TravStack {
+  uint32_t* lds;  // this lane's column of the block's LDS stack (stride CHIP_BLOCK)
+  uint32_t* ovf;  // this thread's global spill slab
+  int sp;
+  uint32_t overflow;
+};
+struct TravCounters {
+  uint32_t bvh, prim;
+};
+
+__device__ inline void st_push(TravStack& s, uint32_t v) {
+  if (s.sp < CHIP_STACK_LDS) s.lds[s.sp * CHIP_BLOCK] = v;
+  else if (s.sp < CHIP_STACK_LDS + CHIP_STACK_OVF) s.ovf[s.sp - CHIP_STACK_LDS] = v;
+  else { s.overflow = 1; return; }
+  s.sp++;
+}
+__device__ inline uint32_t st_pop(TravStack& s, int base) {
+  if (s.sp <= base) return NREF_NONE;
+  s.sp--;
+  return s.sp < CHIP_STACK_LDS ? s.lds[s.sp * CHIP_BLOCK] : s.ovf[s.sp - CHIP_STACK_LDS];
+}
+
+// aabb.rs:195-228.  The per-axis early return is folded into one final test: the
+// running interval only ever narrows and NaN candidates are never stored, so
+// "max <= min after some axis" holds at the end iff it held after that axis.
+__device__ inline bool aabb_hit(const double* b, const TravRay& r, double tmin, double tmax) {
+#define CHIP_SLAB(lo, hi, o, inv)            \
+  {                                          \
+    double t0 = ((lo) - (o)) * (inv);        \
+    double t1 = ((hi) - (o)) * (inv);        \
+    if (t0 < t1) {                           \
+      if (t0 > tmin) tmin = t0;              \
+      if (t1 < tmax) tmax = t1;              \
+    } else {                                 \
+      if (t1 > tmin) tmin = t1;              \
+      if (t0 < tmax) tmax = t0;              \
+    }                                        \
+  }
+  CHIP_SLAB(b[0], b[1], r.o.x, r.inv.x)
+  CHIP_SLAB(b[2], b[3], r.o.y, r.inv.y)
+  CHIP_SLAB(b[4], b[5], r.o.z, r.inv.z)
+#undef CHIP_SLAB
+  return !(tmax <= tmin);
+}
+
+// sphere.rs:99-121: nearest root strictly inside (tmin, tmax)
+__device__ inline bool sphere_hit(const DSphere& s, const TravRay& r, double tmin, double tmax, double& t_out) {
+  V3 center = ld3(s.c) + (r.time * ld3(s.dc));
+  V3 oc = center - r.o;
+  double a = len2(r.d);
+  double h = dot(r.d, oc);
+  double c = len2(oc) - s.r * s.r;
+  double disc = h * h - a * c;
+  if (disc < 0.0) return false;
+  double sq = sqrt(disc);
+  double root = (h - sq) / a;
+  if (!(tmin < root && root < tmax)) {
+    root = (h + sq) / a;
+    if (!(tmin < root && root < tmax)) return false;
+  }
+  t_out = root;
+  return true;
+}
+// quad.rs:144-169: t inside [tmin, tmax] inclusive, plane coordinates inside [0,1] inclusive
+__device__ inline bool quad_hit(const DQuad& q, const TravRay& r, double tmin, double tmax, double& t_out, double& alpha, double& beta) {
+  V3 n = ld3(q.n);
+  double denom = dot(n, r.d);
+  if (fabs(denom) < 1e-8) return false;
+  double t = (q.d - dot(n, r.o)) / denom;
+  if (!(tmin <= t && t <= tmax)) return false;
+  V3 p = r.o + (t * r.d);
+  V3 planar = p - ld3(q.q);
+  V3 w = ld3(q.w);
+  alpha = dot(w, cross(planar, ld3(q.v)));
+  beta = dot(w, cross(ld3(q.u), planar));
+  if (!(0.0 <= alpha && alpha <= 1.0) || !(0.0 <= beta && beta <= 1.0)) return false;
+  t_out = t;
+  return true;
+}
+
+__device__ inline void ray_set_inv(TravRay& r) { r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z); }
+// translate.rs:28 / rotate.rs:137-138
+__device__ inline void apply_xform(const DScene& S, nref_t x, V3& o, V3& d) {
+  if (NREF_KIND(x) == NK_TRANSLATE) {
+    o = o - ld3(S.translates[NREF_INDEX(x)].off);
+  } else {
+    const double* m = S.rotates[NREF_INDEX(x)].m;
+    o = mat_mulT(m, o);
+    d = mat_mulT(m, d);
+  }
+}
+__device__ inline void xform_chain(const DScene& S, nref_t x, uint32_t& first, uint32_t& n) {
+  if (x == NREF_NONE) { first = 0; n = 0; }
+  else if (NREF_KIND(x) == NK_TRANSLATE) { first = S.translates[NREF_INDEX(x)].chain_first; n = S.translates[NREF_INDEX(x)].chain_len; }
+  else { first = S.rotates[NREF_INDEX(x)].chain_first; n = S.rotates[NREF_INDEX(x)].chain_len; }
+}
+// Ray in the space below transform x: replay x's root->self chain on the world ray.
+__device__ inline void ray_to_space(const DScene& S, nref_t x, V3 wo, V3 wd, V3& o, V3& d) {
+  o = wo; d = wd;
+  uint32_t first, n;
+  xform_chain(S, x, first, n);
+  for (uint32_t i = 0; i < n; i++) apply_xform(S, S.xchain[first + i], o, d);
+}
+
+// Closest hit below `start` for the ray in r, over (tmin, best_t]; best_t doubles as
+// the shrinking interval maximum of bvh.rs:66-70 / group.rs:47-52.  MEDIA = the subtree
+// may contain ConstantMedium nodes (a medium's boundary subtree may not).
+template <bool MEDIA>
+__device__ void traverse(const DScene& S, nref_t start, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng, TravStack& st,
+                         TravCounters& cnt);
+
+__device__ __noinline__ void traverse_boundary(const DScene& S, nref_t start, TravRay& r, double tmin, double& best_t, nref_t& best,
+                                               Rng& rng, TravStack& st, TravCounters& cnt) {
+  traverse<false>(S, start, r, tmin, best_t, best, rng, st, cnt);
+}
+
+template <bool MEDIA>
+__device__ void traverse(const DScene& S, nref_t start, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng, TravStack& st,
+                         TravCounters& cnt) {
+  const int base = st.sp;
+  nref_t node = start;
+  while (node != NREF_NONE) {
+    uint32_t kind = NREF_KIND(node), idx = NREF_INDEX(node);
+    if (kind == NK_BVH) {
+      const DBvhNode& n = S.bvh[idx];
+      cnt.bvh++;
+      if (aabb_hit(n.box, r, tmin, best_t)) {
+        st_push(st, n.right);
+        node = n.left;
+        continue;
+      }
+    } else if (kind == NK_SPHERE) {
+      double t;
+      cnt.prim++;
+      if (sphere_hit(S.spheres[idx], r, tmin, best_t, t)) { best_t = t; best = node; }
+    } else if (kind == NK_QUAD) {
+      double t, al, be;
+      cnt.prim++;
+      if (quad_hit(S.quads[idx], r, tmin, best_t, t, al, be)) { best_t = t; best = node; }
+    } else if (kind == NK_GROUP || kind == NK_GROUP_CONT) {
+      // group.rs:44-54: children in order, each over the shrinking interval.  Primitive
+      // children are tested inline; any other child is descended into, leaving a
+      // (position, continuation) pair on the stack.
+      uint32_t pos = 0;
+      if (kind == NK_GROUP_CONT) pos = st_pop(st, base);
+      const DGroup g = S.groups[idx];
+      nref_t descend = NREF_NONE;
+      for (; pos < g.count; pos++) {
+        nref_t c = S.gchild[g.first + pos];
+        uint32_t ck = NREF_KIND(c);
+        if (ck == NK_SPHERE) {
+          double t;
+          cnt.prim++;
+          if (sphere_hit(S.spheres[NREF_INDEX(c)], r, tmin, best_t, t)) { best_t = t; best = c; }
+        } else if (ck == NK_QUAD) {
+          double t, al, be;
+          cnt.prim++;
+          if (quad_hit(S.quads[NREF_INDEX(c)], r, tmin, best_t, t, al, be)) { best_t = t; best = c; }
+        } else {
+          if (pos + 1 < g.count) {
+            st_push(st, pos + 1);
+            st_push(st, NREF(NK_GROUP_CONT, idx));
+          }
+          descend = c;
+          break;
+        }
+      }
+      if (descend != NREF_NONE) { node = descend; continue; }
+    } else if (kind == NK_TRANSLATE) {
+      const DTranslate& t = S.translates[idx];
+      st_push(st, NREF(NK_EXIT_TRANSLATE, idx));
+      r.o = r.o - ld3(t.off);
+      node = t.child;
+      continue;
+    } else if (kind == NK_ROTATE) {
+      const DRotate& t = S.rotates[idx];
+      st_push(st, NREF(NK_EXIT_ROTATE, idx));
+      r.o = mat_mulT(t.m, r.o);
+      r.d = mat_mulT(t.m, r.d);
+      ray_set_inv(r);
+      node = t.child;
+      continue;
+    } else if (kind == NK_EXIT_TRANSLATE || kind == NK_EXIT_ROTATE) {
+      nref_t px = kind == NK_EXIT_TRANSLATE ? S.translates[idx].parent_xform : S.rotates[idx].parent_xform;
+      ray_to_space(S, px, r.wo, r.wd, r.o, r.d);
+      ray_set_inv(r);
+    } else if (MEDIA && kind == NK_MEDIUM) {
+      // constant_medium.rs:41-80
+      const DMedium m = S.media[idx];
+      double t1 = INFINITY, t2 = INFINITY;
+      nref_t b1 = NREF_NONE, b2 = NREF_NONE;
+      traverse_boundary(S, m.boundary, r, -INFINITY, t1, b1, rng, st, cnt);
+      if (b1 != NREF_NONE) {
+        traverse_boundary(S, m.boundary, r, t1 + 0.0001, t2, b2, rng, st, cnt);
+        if (b2 != NREF_NONE) {
+          if (t1 < tmin) t1 = tmin;
+          if (t2 > best_t) t2 = best_t;
+          if (!(t1 >= t2)) {
+            if (t1 < 0.0) t1 = 0.0;
+            double ray_length = len(r.d);
+            double inside = (t2 - t1) * ray_length;
+            double hit_distance = m.neg_inv_density * log(rng.next());
+            if (!(hit_distance > inside)) {
+              best_t = t1 + hit_distance / ray_length;
+              best = node;
+            }
+          }
+        }
+      }
+    }
+    node = st_pop(st, base);
+  }
+}
+
+struct HitOut {
+  V3 pt, n;
+  double u, v;
+  uint32_t mat;
+  int32_t leaf_id;
+  bool front;
+};
+
+// sphere.rs:70-83
+__device__ inline void sphere_uv(V3 p, double& u, double& v) {
+  double theta = acos(-p.y);
+  double phi = atan2(-p.z, p.x) + CHIP_PI;
+  u = phi / (2.0 * CHIP_PI);
+  v = theta / CHIP_PI;
+}
+
+// Builds the HitRecord (object/mod.rs:31-51) of the winning node: recompute the ray in
+// the node's space, the record there (sphere.rs:122-134, quad.rs:159-181,
+// constant_medium.rs:70-79), then carry it back out through the enclosing
+// Translate / Rotate nodes (translate.rs:34, rotate.rs:145-146).
+__device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo, V3 wd, double time, HitOut& h) {
+  uint32_t kind = NREF_KIND(leaf), idx = NREF_INDEX(leaf);
+  nref_t x = kind == NK_SPHERE ? S.spheres[idx].xform : (kind == NK_QUAD ? S.quads[idx].xform : S.media[idx].xform);
+  V3 o, d;
+  ray_to_space(S, x, wo, wd, o, d);
+  h.pt = o + (t * d);
+  if (kind == NK_SPHERE) {
+    const DSphere& s = S.spheres[idx];
+    V3 center = ld3(s.c) + (time * ld3(s.dc));
+    V3 outward = (h.pt - center) / s.r;
+    sphere_uv(outward, h.u, h.v);
+    h.front = dot(d, outward) < 0.0;
+    h.n = h.front ? outward : -outward;
+    h.mat = s.mat;
+    h.leaf_id = s.leaf_id;
+  } else if (kind == NK_QUAD) {
+    const DQuad& q = S.quads[idx];
+    V3 planar = h.pt - ld3(q.q);
+    V3 w = ld3(q.w);
+    h.u = dot(w, cross(planar, ld3(q.v)));
+    h.v = dot(w, cross(ld3(q.u), planar));
+    V3 n = ld3(q.n);
+    h.front = dot(d, n) < 0.0;
+    h.n = h.front ? n : -n;
+    h.mat = q.mat;
+    h.leaf_id = q.leaf_id;
+  } else {
+    const DMedium& m = S.media[idx];
+    h.n = mk(1.0, 0.0, 0.0);
+    h.u = 0.0;
+    h.v = 0.0;
+    h.front = true;
+    h.mat = m.mat;
+    h.leaf_id = m.leaf_id;
+  }
+  uint32_t first, n;
+  xform_chain(S, x, first, n);
+  for (uint32_t i = n; i > 0; i--) {
+    nref_t xf = S.xchain[first + i - 1];
+    if (NREF_KIND(xf) == NK_TRANSLATE) {
+      h.pt = h.pt + ld3(S.translates[NREF_INDEX(xf)].off);
+    } else {
+      const double* m = S.rotates[NREF_INDEX(xf)].m;
+      h.pt = mat_mul(m, h.pt);
+      h.n = mat_mul(m, h.n);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ textures (texture/*.rs, utils/perlin.rs)
+__device__ inline double perlin_noise(const DPerlin& P, V3 pt) {  // perlin.rs:101-124,181-198
+  double fx = floor(pt.x), fy = floor(pt.y), fz = floor(pt.z);
+  double u = pt.x - fx, v = pt.y - fy, w = pt.z - fz;
+  long long i = (long long)fx, j = (long long)fy, k = (long long)fz;
+  double uu = u * u * (3.0 - 2.0 * u);
+  double vv = v * v * (3.0 - 2.0 * v);
+  double ww = w * w * (3.0 - 2.0 * w);
+  double acc = 0.0;
+  for (int di = 0; di < 2; di++)
+    for (int dj = 0; dj < 2; dj++)
+      for (int dk = 0; dk < 2; dk++) {
+        int idx = P.perm_x[(i + di) & 255] ^ P.perm_y[(j + dj) & 255] ^ P.perm_z[(k + dk) & 255];
+        V3 c = ld3(&P.rand_vec[3 * idx]);
+        V3 wv = mk(u - (double)di, v - (double)dj, w - (double)dk);
+        acc += ((double)di * uu + (1.0 - (double)di) * (1.0 - uu)) * ((double)dj * vv + (1.0 - (double)dj) * (1.0 - vv)) *
+               ((double)dk * ww + (1.0 - (double)dk) * (1.0 - ww)) * dot(c, wv);
+      }
+  return acc;
+}
+__device__ inline double perlin_turbulence(const DPerlin& P, V3 pt, uint32_t depth) {  // perlin.rs:151-163
+  double acc = 0.0, weight = 1.0;
+  V3 p = pt;
+  for (uint32_t i = 0; i < depth; i++) {
+    acc += weight * perlin_noise(P, p);
+    weight *= 0.5;
+    p = p * 2.0;
+  }
+  return fabs(acc);
+}
+__device__ inline double rclamp(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }  // f64::clamp
+__device__ inline V3 tex_value(const DScene& S, int tex, double u, double v, V3 pt) {
+  for (int guard = 0; guard < 64; guard++) {
+    const DTexture& T = S.textures[tex];
+    switch (T.kind) {
+      case TK_SOLID: return mk(T.p[0], T.p[1], T.p[2]);  // solid_color.rs:14-17
+      case TK_CHECKER: {                                  // checker_texture.rs:22-35
+        long long xi = (long long)floor(T.p[0] * pt.x);
+        long long yi = (long long)floor(T.p[0] * pt.y);
+        long long zi = (long long)floor(T.p[0] * pt.z);
+        tex = ((xi + yi + zi) % 2 == 0) ? (int)T.a : (int)T.b;
+        break;
+      }
+      case TK_IMAGE: {  // image_texture.rs:16-29, image.rs:58-66
+        double uc = rclamp(u, 0.0, 1.0);
+        double vc = 1.0 - rclamp(v, 0.0, 1.0);
+        uint32_t i = (uint32_t)(uc * (double)T.a);
+        uint32_t j = (uint32_t)(vc * (double)T.b);
+        if (i >= T.a || j >= T.b) return mk(0.0, 1.0, 1.0);
+        const uint8_t* p = S.texels + T.c + ((size_t)j * T.a + i) * 3;
+        return mk((double)p[0] / 255.0, (double)p[1] / 255.0, (double)p[2] / 255.0);
+      }
+      case TK_NOISE: {  // perlin_noise.rs:18-22
+        double s = 0.5 * (1.0 + perlin_noise(S.perlins[T.a], T.p[0] * pt));
+        return mk(s, s, s);
+      }
+      default: {  // TK_TURBULENCE, perlin_turbulence.rs:20-27
+        double s = 0.5 * (1.0 + sin(T.p[0] * pt.z + 10.0 * perlin_turbulence(S.perlins[T.a], pt, T.b)));
+        return mk(s, s, s);
+      }
+    }
+  }
+  return mk(0, 0, 0);
+}
+
+// ------------------------------------------------------------------ light sampling (quad.rs:210-245, sphere.rs:85-95,143-170, group.rs:60-78)
+__device__ inline double light_pdf_one(const DScene& S, const DLight& L, V3 origin, V3 dir) {
+  TravRay r;
+  r.o = origin; r.d = dir; r.time = 0.0;  // Ray::new -> time 0
+  if (L.kind == LK_SPHERE) {
+    const DSphere& s = S.spheres[L.index];
+    double t;
+    if (!sphere_hit(s, r, 0.001, INFINITY, t)) return 0.0;
+    double dist2 = len2(ld3(s.c) - origin);
+    double cos_theta_max = sqrt(1.0 - s.r * s.r / dist2);
+    double solid_angle = 2.0 * CHIP_PI * (1.0 - cos_theta_max);
+    return 1.0 / solid_angle;
+  } else if (L.kind == LK_QUAD) {
+    const DQuad& q = S.quads[L.index];
+    double t, al, be;
+    if (!quad_hit(q, r, 0.001, INFINITY, t, al, be)) return 0.0;
+    V3 n = ld3(q.n);
+    V3 hn = dot(dir, n) < 0.0 ? n : -n;
+    double distance_squared = t * t * len2(dir);
+    double cosine = fabs(dot(dir, hn) / len(dir));
+    return distance_squared / (cosine * q.area);
+  }
+  return 0.0;  // Node::pdf_value default, object/mod.rs:59-61
+}
+__device__ inline V3 light_random_one(const DScene& S, const DLight& L, V3 origin, Rng& rng) {
+  if (L.kind == LK_SPHERE) {
+    const DSphere& s = S.spheres[L.index];
+    V3 direction = ld3(s.c) - origin;
+    double distance_squared = len2(direction);
+    Onb uvw(direction);
+    double r1 = rng.next();
+    double r2 = rng.next();
+    double z = 1.0 + r2 * (sqrt(1.0 - s.r * s.r / distance_squared) - 1.0);
+    double phi = 2.0 * CHIP_PI * r1;
+    double x = cos(phi) * sqrt(1.0 - z * z);
+    double y = sin(phi) * sqrt(1.0 - z * z);
+    return uvw.local(mk(x, y, z));
+  } else if (L.kind == LK_QUAD) {
+    const DQuad& q = S.quads[L.index];
+    double r1 = rng.next();
+    double r2 = rng.next();
+    V3 p = ld3(q.q) + (r1 * ld3(q.u)) + (r2 * ld3(q.v));
+    return p - origin;
+  }
+  return mk(1.0, 0.0, 0.0);  // Node::random default, object/mod.rs:63-65
+}
+__device__ inline double lights_pdf(const DScene& S, V3 origin, V3 dir) {
+  if (!S.lights_is_group) return light_pdf_one(S, S.lights[0], origin, dir);
+  double weight = 1.0 / (double)S.n_lights;
+  double sum = 0.0;
+  for (uint32_t i = 0; i < S.n_lights; i++) sum += weight * light_pdf_one(S, S.lights[i], origin, dir);
+  return sum;
+}
+__device__ inline V3 lights_random(const DScene& S, V3 origin, Rng& rng) {
+  if (!S.lights_is_group) return light_random_one(S, S.lights[0], origin, rng);
+  if (S.n_lights == 0) return mk(0.0, 1.0, 0.0);
+  uint32_t i = (uint32_t)(long long)(rng.next() * (double)S.n_lights);  // rand_int_interval(0, len)
+  if (i >= S.n_lights) i = S.n_lights - 1;
+  return light_random_one(S, S.lights[i], origin, rng);
+}
+
+// ------------------------------------------------------------------ queue helpers (wave64 ballot + prefix popcount)
+__device__ inline void queue_push(uint32_t* q, uint32_t* counter, bool pred, uint32_t value) {
+  unsigned long long mask = __ballot(pred);
+  if (mask == 0) return;
+  uint32_t lane = __lane_id();
+  uint32_t leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (pred) {
+    uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+    q[base + rank] = value;
+  }
+}
+
+__device__ inline float fclampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }  // keeps NaN like f64::clamp
+
+struct Affine {
+  float a[3], b[3], lo[3], hi[3];
+};
+__device__ inline void affine_load(const PathPool& P, uint32_t slot, Affine& f) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    f.a[c] = P.st[(size_t)(0 + c) * P.cap + slot];
+    f.b[c] = P.st[(size_t)(3 + c) * P.cap + slot];
+    f.lo[c] = P.st[(size_t)(6 + c) * P.cap + slot];
+    f.hi[c] = P.st[(size_t)(9 + c) * P.cap + slot];
+  }
+}
+__device__ inline void affine_store(const PathPool& P, uint32_t slot, const Affine& f) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    P.st[(size_t)(0 + c) * P.cap + slot] = f.a[c];
+    P.st[(size_t)(3 + c) * P.cap + slot] = f.b[c];
+    P.st[(size_t)(6 + c) * P.cap + slot] = f.lo[c];
+    P.st[(size_t)(9 + c) * P.cap + slot] = f.hi[c];
+  }
+}
+// One bounce of camera.rs:274-304 as the per-channel map x -> clamp(e + w x, klo, khi),
+// composed on the right of the path's x -> clamp(a + b x, lo, hi).
+__device__ inline void affine_compose(Affine& f, const float e[3], const float w[3], float klo, float khi) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float p = f.a[c] + f.b[c] * klo, q = f.a[c] + f.b[c] * khi;
+    float nlo = fclampf(p < q ? p : q, f.lo[c], f.hi[c]);
+    float nhi = fclampf(p < q ? q : p, f.lo[c], f.hi[c]);
+    f.a[c] = f.a[c] + f.b[c] * e[c];
+    f.b[c] = f.b[c] * w[c];
+    f.lo[c] = nlo;
+    f.hi[c] = nhi;
+  }
+}
+__device__ inline void finish_path(const PathPool& P, uint32_t slot, const Affine& f, const float x[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) P.sample[(size_t)c * P.cap + slot] = fclampf(f.a[c] + f.b[c] * x[c], f.lo[c], f.hi[c]);
+}
+
+__device__ inline void slot_to_path(const BatchDesc& B, const DCamera& cam, uint32_t slot, uint32_t& x, uint32_t& y, uint32_t& pixel,
+                                    uint32_t& stratum) {
+  uint32_t sb = slot / B.npix, p = slot - sb * B.npix;
+  y = B.rect_y0 + p / B.rect_w;
+  x = B.rect_x0 + p % B.rect_w;
+  pixel = y * cam.image_width + x;
+  stratum = B.stratum_first + sb * B.stratum_stride;
+}
+
+// camera.rs:359-374,389-394,416-419 with vector.rs:115-126
+__device__ inline void camera_ray(const DCamera& cam, Rng& rng, uint32_t x, uint32_t y, uint32_t s_x, uint32_t s_y, V3& o, V3& d,
+                                  double& time) {
+  double px = (((double)s_x + rng.next()) * cam.recip_sqrt_spp) - 0.5;
+  double py = (((double)s_y + rng.next()) * cam.recip_sqrt_spp) - 0.5;
+  V3 pixel_sample = ld3(cam.pixel00) + (((double)x + px) * ld3(cam.du)) + (((double)y + py) * ld3(cam.dv));
+  if (cam.defocus_angle <= 0.0) {
+    o = ld3(cam.center);
+  } else {
+    double dx = 0, dy = 0;
+    for (int it = 0; it < CHIP_REJECT_CAP; it++) {
+      dx = rng.interval(-1.0, 1.0);
+      dy = rng.interval(-1.0, 1.0);
+      double xs = dx * dx, ys = dy * dy, zs = 0.0 * 0.0;
+      if (xs + ys + zs < 1.0) break;
+    }
+    o = ld3(cam.center) + (dx * ld3(cam.disk_u)) + (dy * ld3(cam.disk_v));
+  }
+  d = pixel_sample - o;
+  time = rng.next();
+}
+
+// ------------------------------------------------------------------ kernels
+__global__ void __launch_bounds__(CHIP_BLOCK) k_raygen(DScene S, PathPool P, BatchDesc B) {
+  for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < B.n_paths; slot += gridDim.x * blockDim.x) {
+    uint32_t x, y, pixel, stratum;
+    slot_to_path(B, S.cam, slot, x, y, pixel, stratum);
+    Rng rng;
+    rng.init(B.seed_lo, B.seed_hi, pixel, stratum, CHIP_CAMERA_BOUNCE, 0);
+    V3 o, d;
+    double time;
+    camera_ray(S.cam, rng, x, y, stratum % S.cam.sqrt_spp, stratum / S.cam.sqrt_spp, o, d, time);
+    size_t cap = P.cap;
+    P.ray[0 * cap + slot] = o.x; P.ray[1 * cap + slot] = o.y; P.ray[2 * cap + slot] = o.z;
+    P.ray[3 * cap + slot] = d.x; P.ray[4 * cap + slot] = d.y; P.ray[5 * cap + slot] = d.z;
+    P.ray[6 * cap + slot] = time;
+    Affine f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { f.a[c] = 0.f; f.b[c] = 1.f; f.lo[c] = -CHIP_BIG; f.hi[c] = CHIP_BIG; }
+    affine_store(P, slot, f);
+    P.sample[0 * cap + slot] = 0.f; P.sample[1 * cap + slot] = 0.f; P.sample[2 * cap + slot] = 0.f;
+    P.q_live[0][slot] = slot;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[0] = B.n_paths;
+}
+
+// One world.hit (camera.rs:264) per live path: traversal, HitRecord, binning by material kind.
+template <bool MEDIA>
+__global__ void __launch_bounds__(CHIP_BLOCK) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce) {
+  __shared__ uint32_t lds_stack[CHIP_STACK_LDS * CHIP_BLOCK];
+  const uint32_t* q_in = P.q_live[bounce & 1];
+  uint32_t* ctr = P.counters + (size_t)bounce * 8;
+  const uint32_t n_live = ctr[0];
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  TravStack st;
+  st.lds = lds_stack + threadIdx.x;
+  st.ovf = P.ovf + (size_t)gtid * CHIP_STACK_OVF;
+  st.overflow = 0;
+  TravCounters cnt{0, 0};
+  uint32_t nseg = 0;
+  const size_t cap = P.cap;
+  // whole waves iterate together so the ballots in queue_push see uniform control flow
+  const uint32_t n_round = (n_live + 63u) & ~63u;
+  for (uint32_t i = gtid; i < n_round; i += gridDim.x * blockDim.x) {
+    const bool active = i < n_live;
+    uint32_t slot = 0, kind = MK_COUNT;
+    if (active) {
+      slot = q_in[i];
+      TravRay r;
+      r.wo = mk(P.ray[0 * cap + slot], P.ray[1 * cap + slot], P.ray[2 * cap + slot]);
+      r.wd = mk(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
+      r.time = P.ray[6 * cap + slot];
+      r.o = r.wo; r.d = r.wd;
+      ray_set_inv(r);
+      uint32_t x, y, pixel, stratum;
+      slot_to_path(B, S.cam, slot, x, y, pixel, stratum);
+      Rng rng;
+      rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, 0);
+      double best_t = INFINITY;
+      nref_t best = NREF_NONE;
+      st.sp = 0;
+      traverse<MEDIA>(S, S.root, r, 0.001, best_t, best, rng, st, cnt);
+      nseg++;
+      if (best == NREF_NONE) {
+        Affine f;
+        affine_load(P, slot, f);
+        float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
+        finish_path(P, slot, f, bg);
+      } else {
+        HitOut h;
+        reconstruct(S, best, best_t, r.wo, r.wd, r.time, h);
+        P.hit[0 * cap + slot] = best_t;
+        P.hit[1 * cap + slot] = h.pt.x; P.hit[2 * cap + slot] = h.pt.y; P.hit[3 * cap + slot] = h.pt.z;
+        P.hit[4 * cap + slot] = h.n.x; P.hit[5 * cap + slot] = h.n.y; P.hit[6 * cap + slot] = h.n.z;
+        P.hit[7 * cap + slot] = h.u; P.hit[8 * cap + slot] = h.v;
+        P.hinfo[slot] = h.mat | (h.front ? 0x80000000u : 0u);
+        P.draw[slot] = rng.draw;
+        kind = S.materials[h.mat].kind;
+      }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < MK_COUNT; k++) queue_push(P.q_mat + (size_t)k * cap, &ctr[1 + k], kind == k, slot);
+  }
+  if (st.overflow) atomicOr(&P.errflag[0], 1u);
+  // per-wave reduction of the traversal counters
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt.bvh += __shfl_down(cnt.bvh, off);
+    cnt.prim += __shfl_down(cnt.prim, off);
+    nseg += __shfl_down(nseg, off);
+  }
+  if (__lane_id() == 0 && nseg) {
+    atomicAdd(&P.stats[0], (unsigned long long)nseg);
+    atomicAdd(&P.stats[1], (unsigned long long)cnt.bvh);
+    atomicAdd(&P.stats[2], (unsigned long long)cnt.prim);
+  }
+}
+
+// Material-binned shade: Material::emitted / scatter / scattering_pdf plus the PDF branch of
+// camera.rs:278-305 for one material kind.
+template <uint32_t KIND>
+__global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, BatchDesc B, uint32_t bounce) {
+  uint32_t* ctr = P.counters + (size_t)bounce * 8;
+  uint32_t* ctr_next = P.counters + (size_t)(bounce + 1) * 8;
+  const uint32_t n = ctr[1 + KIND];
+  const uint32_t* q = P.q_mat + (size_t)KIND * P.cap;
+  uint32_t* q_out = P.q_live[(bounce + 1) & 1];
+  const size_t cap = P.cap;
+  const bool last_bounce = bounce + 1 >= S.cam.max_depth;
+  const uint32_t n_round = (n + 63u) & ~63u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+    bool cont = false;
+    uint32_t slot = 0;
+    if (i < n) {
+      slot = q[i];
+      Affine f;
+      affine_load(P, slot, f);
+      const uint32_t hinfo = P.hinfo[slot];
+      const bool front = hinfo >> 31;
+      const DMaterial& M = S.materials[hinfo & 0x7FFFFFFFu];
+      V3 pt = mk(P.hit[1 * cap + slot], P.hit[2 * cap + slot], P.hit[3 * cap + slot]);
+      if (KIND == MK_DIFFUSE_LIGHT) {
+        // diffuse_light.rs:28-43: no scatter; emits on the front face only
+        float x[3] = {0.f, 0.f, 0.f};
+        if (front) {
+          V3 e = tex_value(S, M.tex, P.hit[7 * cap + slot], P.hit[8 * cap + slot], pt);
+          x[0] = (float)e.x; x[1] = (float)e.y; x[2] = (float)e.z;
+        }
+        finish_path(P, slot, f, x);
+      } else if (KIND == MK_EMPTY) {
+        float x[3] = {0.f, 0.f, 0.f};  // empty.rs:18-27 + default emitted
+        finish_path(P, slot, f, x);
+      } else {
+        V3 nrm = mk(P.hit[4 * cap + slot], P.hit[5 * cap + slot], P.hit[6 * cap + slot]);
+        V3 rd = mk(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
+        uint32_t x_, y_, pixel, stratum;
+        slot_to_path(B, S.cam, slot, x_, y_, pixel, stratum);
+        Rng rng;
+        rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, P.draw[slot]);
+        V3 ndir;
+        bool terminal = false;
+        float e[3] = {0.f, 0.f, 0.f}, w[3];
+        float klo = -CHIP_BIG, khi = CHIP_BIG;
+        if (KIND == MK_METAL) {  // metal.rs:20-28
+          V3 reflected = reflect(rd, nrm);
+          ndir = unit(reflected) + (M.p[3] * random_unit(rng));
+          w[0] = (float)M.p[0]; w[1] = (float)M.p[1]; w[2] = (float)M.p[2];
+        } else if (KIND == MK_DIELECTRIC) {  // dielectric.rs:30-52
+          double ri = front ? 1.0 / M.p[0] : M.p[0];
+          V3 ud = unit(rd);
+          double cos_theta = fmin(dot(-ud, nrm), 1.0);
+          double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+          bool cannot_refract = ri * sin_theta > 1.0;
+          bool refl = cannot_refract;
+          if (!refl) {
+            double r0 = (1.0 - ri) / (1.0 + ri);
+            r0 = r0 * r0;
+            double x1 = 1.0 - cos_theta;
+            double x2 = x1 * x1;
+            double x4 = x2 * x2;
+            double reflectance = r0 + (1.0 - r0) * (x4 * x1);
+            refl = reflectance > rng.next();
+          }
+          ndir = refl ? reflect(ud, nrm) : refract(ud, nrm, ri);
+          w[0] = 1.f; w[1] = 1.f; w[2] = 1.f;
+        } else {
+          // Lambertian (lambertian.rs:29-49) / Isotropic (isotropic.rs:29-44): PDF branch, camera.rs:278-305
+          V3 atten = tex_value(S, M.tex, P.hit[7 * cap + slot], P.hit[8 * cap + slot], pt);
+          bool use_light = false;
+          if (S.has_lights) use_light = rng.next() < 0.5;  // mixture.rs:26-32
+          Onb uvw(nrm);                                    // cosine.rs:10-14 (unused for Isotropic)
+          if (use_light) ndir = lights_random(S, pt, rng);
+          else if (KIND == MK_LAMBERTIAN) ndir = uvw.local(random_cosine_direction(rng));  // cosine.rs:24-27
+          else ndir = random_unit(rng);                                                   // probability_density_function/sphere.rs:24-26
+          double mat_pdf;
+          if (KIND == MK_LAMBERTIAN) mat_pdf = fmax(dot(unit(ndir), uvw.w) / CHIP_PI, 0.0);  // cosine.rs:18-22
+          else mat_pdf = 1.0 / (4.0 * CHIP_PI);                                              // sphere.rs:20-22
+          double pv = mat_pdf;
+          if (S.has_lights) {  // mixture.rs:20-24
+            double v0 = 0.5 * lights_pdf(S, pt, ndir);
+            double v1 = 0.5 * mat_pdf;
+            pv = v0 + v1;
+          }
+          if (pv < 0.05) {  // camera.rs:291-293: returns the emission (zero for these materials)
+            terminal = true;
+          } else {
+            double sp;
+            if (KIND == MK_LAMBERTIAN) {
+              double cos_theta = dot(nrm, unit(ndir));
+              sp = cos_theta < 0.0 ? 0.0 : cos_theta / CHIP_PI;
+            } else {
+              sp = 1.0 / (4.0 / CHIP_PI);  // isotropic.rs:43
+            }
+            w[0] = (float)(atten.x * sp / pv); w[1] = (float)(atten.y * sp / pv); w[2] = (float)(atten.z * sp / pv);
+            klo = 0.f; khi = 10.f;  // camera.rs:304
+          }
+        }
+        if (terminal) {
+          float x[3] = {0.f, 0.f, 0.f};
+          finish_path(P, slot, f, x);
+        } else {
+          affine_compose(f, e, w, klo, khi);
+          if (last_bounce) {
+            float x[3] = {0.f, 0.f, 0.f};  // camera.rs:259-261
+            finish_path(P, slot, f, x);
+          } else {
+            affine_store(P, slot, f);
+            P.ray[0 * cap + slot] = pt.x; P.ray[1 * cap + slot] = pt.y; P.ray[2 * cap + slot] = pt.z;
+            P.ray[3 * cap + slot] = ndir.x; P.ray[4 * cap + slot] = ndir.y; P.ray[5 * cap + slot] = ndir.z;
+            cont = true;
+          }
+        }
+      }
+    }
+    if (KIND != MK_DIFFUSE_LIGHT && KIND != MK_EMPTY) queue_push(q_out, &ctr_next[0], cont, slot);
+  }
+}
+
+// Adds this batch's finished samples into the rectangle's f32 radiance sum, strata in
+// ascending order per pixel (camera.rs:335-341's `pixel_color += sample`).
+__global__ void __launch_bounds__(CHIP_BLOCK) k_accumulate(PathPool P, BatchDesc B, float* sum_rgb) {
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < B.npix; p += gridDim.x * blockDim.x) {
+    float r = 0.f, g = 0.f, b = 0.f;
+    for (uint32_t sb = 0; sb < B.n_strata; sb++) {
+      size_t slot = (size_t)sb * B.npix + p;
+      r += P.sample[0 * (size_t)P.cap + slot];
+      g += P.sample[1 * (size_t)P.cap + slot];
+      b += P.sample[2 * (size_t)P.cap + slot];
+    }
+    sum_rgb[(size_t)p * 3 + 0] += r;
+    sum_rgb[(size_t)p * 3 + 1] += g;
+    sum_rgb[(size_t)p * 3 + 2] += b;
+  }
+}
+
+// camera.rs:343-344 (scale, NaN -> 0 on the sum, gamma = sqrt, clamp to [0, 0.999]) and the
+// 8-bit quantisation of crates/cli/src/main.rs:193-198.
+__global__ void __launch_bounds__(CHIP_BLOCK) k_resolve(const float* sum_rgb, size_t n_values, double scale, float* out_gamma,
+                                                        uint8_t* out_rgb8) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_values; i += (size_t)gridDim.x * blockDim.x) {
+    double v = (double)sum_rgb[i];
+    if (v != v) v = 0.0;
+    v = scale * v;
+    double g = v > 0.0 ? sqrt(v) : 0.0;
+    g = rclamp(g, 0.0, 0.999);
+    if (out_gamma) out_gamma[i] = (float)g;
+    if (out_rgb8) out_rgb8[i] = (uint8_t)(g * 255.999);
+  }
+}
+
+// Test hook: closest hit + HitRecord for caller-supplied rays.
+struct DHitOut {
+  double t, pt[3], normal[3], u, v;
+  int32_t hit, leaf_id, front_face, material_kind;
+};
+template <bool MEDIA>
+__global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P, uint32_t seed_lo, uint32_t seed_hi, uint32_t n,
+                                                           const double* o, const double* d, const double* tm, DHitOut* out) {
+  __shared__ uint32_t lds_stack[CHIP_STACK_LDS * CHIP_BLOCK];
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  TravStack st;
+  st.lds = lds_stack + threadIdx.x;
+  st.ovf = P.ovf + (size_t)gtid * CHIP_STACK_OVF;
+  st.overflow = 0;
+  TravCounters cnt{0, 0};
+  for (uint32_t i = gtid; i < n; i += gridDim.x * blockDim.x) {
+    TravRay r;
+    r.wo = mk(o[3 * (size_t)i], o[3 * (size_t)i + 1], o[3 * (size_t)i + 2]);
+    r.wd = mk(d[3 * (size_t)i], d[3 * (size_t)i + 1], d[3 * (size_t)i + 2]);
+    r.time = tm ? tm[i] : 0.0;
+    r.o = r.wo; r.d = r.wd;
+    ray_set_inv(r);
+    Rng rng;
+    rng.init(seed_lo, seed_hi, i, 0, 0, 0);
+    double best_t = INFINITY;
+    nref_t best = NREF_NONE;
+    st.sp = 0;
+    traverse<MEDIA>(S, S.root, r, 0.001, best_t, best, rng, st, cnt);
+    DHitOut h;
+    h.t = 0; h.u = 0; h.v = 0;
+    for (int k = 0; k < 3; k++) { h.pt[k] = 0; h.normal[k] = 0; }
+    h.hit = 0; h.leaf_id = -1; h.front_face = 0; h.material_kind = -1;
+    if (best != NREF_NONE) {
+      HitOut ho;
+      reconstruct(S, best, best_t, r.wo, r.wd, r.time, ho);
+      h.hit = 1;
+      h.t = best_t;
+      h.pt[0] = ho.pt.x; h.pt[1] = ho.pt.y; h.pt[2] = ho.pt.z;
+      h.normal[0] = ho.n.x; h.normal[1] = ho.n.y; h.normal[2] = ho.n.z;
+      h.u = ho.u; h.v = ho.v;
+      h.leaf_id = ho.leaf_id;
+      h.front_face = ho.front ? 1 : 0;
+      h.material_kind = (int32_t)S.materials[ho.mat].kind;
+    }
+    out[i] = h;
+  }
+  if (st.overflow) atomicOr(&P.errflag[0], 1u);
+}
+
+// Test hook: camera rays for (x, y, s_x, s_y) tuples.
+__global__ void __launch_bounds__(CHIP_BLOCK) k_camera_rays(DScene S, uint32_t seed_lo, uint32_t seed_hi, uint32_t n, const uint32_t* xyss,
+                                                            double* rays) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint32_t x = xyss[4 * (size_t)i], y = xyss[4 * (size_t)i + 1], sx = xyss[4 * (size_t)i + 2], sy = xyss[4 * (size_t)i + 3];
+    Rng rng;
+    rng.init(seed_lo, seed_hi, y * S.cam.image_width + x, sy * S.cam.sqrt_spp + sx, CHIP_CAMERA_BOUNCE, 0);
+    V3 o, d;
+    double time;
+    camera_ray(S.cam, rng, x, y, sx, sy, o, d, time);
+    double* r = rays + 7 * (size_t)i;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = time;
+  }
+}

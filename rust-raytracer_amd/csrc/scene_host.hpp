@@ -1,0 +1,517 @@
+// Host side of libcaustic_hip: the scene graph built through the C ABI, its
+// bounding boxes and BVH (laid out exactly as the reference builds them, so the
+// traversal order and the hit/miss decisions are the reference's), the derived
+// camera, and the flattening of the graph into the SoA tables of device_scene.h.
+// Citations are to the reference, paths relative to crates/core/src/.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/caustic_hip.h"
+#include "device_scene.h"
+
+namespace chip {
+
+constexpr double kInf = std::numeric_limits<double>::infinity();
+constexpr double kPi = 3.14159265358979323846;
+
+// Box as xmin,xmax,ymin,ymax,zmin,zmax.
+struct Box6 {
+  double v[6];
+};
+
+// axis_aligned_bounding_box.rs:273-285 with interval.rs:148-151,163-165
+inline Box6 box_pad(Box6 b) {
+  const double delta = 0.0001;
+  for (int a = 0; a < 3; a++) {
+    if (b.v[2 * a + 1] - b.v[2 * a] < delta) {
+      double padding = delta / 2.0;
+      b.v[2 * a] = b.v[2 * a] - padding;
+      b.v[2 * a + 1] = b.v[2 * a + 1] + padding;
+    }
+  }
+  return b;
+}
+inline Box6 box_empty() { return box_pad(Box6{{kInf, -kInf, kInf, -kInf, kInf, -kInf}}); }  // aabb.rs:41-47
+inline Box6 box_from_points(const double* p, const double* q) {                           // aabb.rs:89-107
+  Box6 b;
+  for (int a = 0; a < 3; a++) {
+    if (p[a] <= q[a]) { b.v[2 * a] = p[a]; b.v[2 * a + 1] = q[a]; }
+    else { b.v[2 * a] = q[a]; b.v[2 * a + 1] = p[a]; }
+  }
+  return box_pad(b);
+}
+inline Box6 box_union(const Box6& x, const Box6& y) {  // aabb.rs:134-140, interval.rs:77-82
+  Box6 b;
+  for (int a = 0; a < 3; a++) {
+    b.v[2 * a] = std::fmin(x.v[2 * a], y.v[2 * a]);
+    b.v[2 * a + 1] = std::fmax(x.v[2 * a + 1], y.v[2 * a + 1]);
+  }
+  return box_pad(b);
+}
+inline int box_longest_axis(const Box6& b) {  // aabb.rs:246-258
+  double sx = b.v[1] - b.v[0], sy = b.v[3] - b.v[2], sz = b.v[5] - b.v[4];
+  if (sx > sy) return sx > sz ? 0 : 2;
+  return sy > sz ? 1 : 2;
+}
+// f64::total_cmp as a strict-weak "less"
+inline bool total_less(double a, double b) {
+  int64_t ia, ib;
+  std::memcpy(&ia, &a, 8);
+  std::memcpy(&ib, &b, 8);
+  ia ^= (int64_t)((uint64_t)(ia >> 63) >> 1);
+  ib ^= (int64_t)((uint64_t)(ib >> 63) >> 1);
+  return ia < ib;
+}
+
+struct HTexture {
+  DTexture d;
+};
+struct HNode {
+  int kind = -1;  // CHIP_NODE_*
+  int id = -1;    // creation id, -1 for internally built nodes
+  Box6 box;
+  double a[17] = {0};  // sphere: c,dc,r | quad: q,u,v,n,w,d,area | translate: off | rotate: m[9] | medium: -1/density
+  int mat = -1;
+  int c0 = -1, c1 = -1;   // bvh: left,right; translate/rotate/medium: child in c0
+  std::vector<int> kids;  // group / box children
+  bool referenced = false;
+};
+
+struct Flat {
+  std::vector<DBvhNode> bvh;
+  std::vector<DSphere> spheres;
+  std::vector<DQuad> quads;
+  std::vector<DGroup> groups;
+  std::vector<nref_t> gchild;
+  std::vector<DTranslate> translates;
+  std::vector<DRotate> rotates;
+  std::vector<DMedium> media;
+  std::vector<nref_t> xchain;
+  std::vector<DLight> lights;
+  nref_t root = NREF_NONE;
+  uint32_t has_lights = 0, lights_is_group = 0;
+};
+
+struct HostScene {
+  std::vector<DTexture> textures;
+  std::vector<DPerlin> perlins;
+  std::vector<uint8_t> texels;
+  std::vector<DMaterial> materials;
+  std::vector<HNode> nodes;       // all host nodes, user-created and internal
+  std::vector<int> handle;        // creation id -> index into nodes
+  int world = -1, lights = -1;    // creation ids
+  bool has_camera = false;
+  chip_camera_desc cam_desc;
+  DCamera cam;
+
+  int add_node(HNode&& n, bool user) {
+    if (user) {
+      n.id = (int)handle.size();
+      handle.push_back((int)nodes.size());
+    }
+    nodes.push_back(std::move(n));
+    return (int)nodes.size() - 1;
+  }
+
+  // ---- constructors (each returns the host index)
+  int make_sphere(const double* c, double r, int mat, bool user) {  // sphere.rs:21-29
+    HNode n;
+    n.kind = CHIP_NODE_SPHERE;
+    for (int i = 0; i < 3; i++) { n.a[i] = c[i]; n.a[3 + i] = 0.0; }
+    n.a[6] = r;
+    n.mat = mat;
+    double lo[3] = {c[0] - r, c[1] - r, c[2] - r}, hi[3] = {c[0] + r, c[1] + r, c[2] + r};
+    n.box = box_from_points(lo, hi);
+    return add_node(std::move(n), user);
+  }
+  void sphere_set_direction(int h, const double* d) {  // sphere.rs:31-47
+    HNode& n = nodes[h];
+    for (int i = 0; i < 3; i++) n.a[3 + i] = d[i];
+    double r = n.a[6];
+    double lo[3], hi[3];
+    // center.at(0.0) = origin + 0.0 * direction, center.at(1.0) = origin + 1.0 * direction (ray.rs:113-115)
+    for (int i = 0; i < 3; i++) { double c0 = n.a[i] + d[i] * 0.0; lo[i] = c0 - r; hi[i] = c0 + r; }
+    Box6 b1 = box_from_points(lo, hi);
+    for (int i = 0; i < 3; i++) { double c1 = n.a[i] + d[i] * 1.0; lo[i] = c1 - r; hi[i] = c1 + r; }
+    Box6 b2 = box_from_points(lo, hi);
+    n.box = box_union(b1, b2);
+  }
+  int make_quad(const double* q, const double* u, const double* v, int mat, bool user) {  // quad.rs:59-96
+    HNode n;
+    n.kind = CHIP_NODE_QUAD;
+    double nx = u[1] * v[2] - u[2] * v[1], ny = u[2] * v[0] - u[0] * v[2], nz = u[0] * v[1] - u[1] * v[0];
+    double nn = nx * nx + ny * ny + nz * nz;  // length_squared order: xs + ys + zs
+    double nl = std::sqrt(nn);
+    double normal[3] = {nx / nl, ny / nl, nz / nl};
+    double d = normal[0] * q[0] + normal[1] * q[1] + normal[2] * q[2];
+    double ndn = nx * nx + ny * ny + nz * nz;  // n.dot(&n)
+    double w[3] = {nx / ndn, ny / ndn, nz / ndn};
+    for (int i = 0; i < 3; i++) {
+      n.a[i] = q[i]; n.a[3 + i] = u[i]; n.a[6 + i] = v[i]; n.a[9 + i] = normal[i]; n.a[12 + i] = w[i];
+    }
+    n.a[15] = d;
+    n.a[16] = nl;  // area = n.length()
+    n.mat = mat;
+    double quv[3], qu[3], qv[3];
+    for (int i = 0; i < 3; i++) { quv[i] = q[i] + u[i] + v[i]; qu[i] = q[i] + u[i]; qv[i] = q[i] + v[i]; }
+    n.box = box_union(box_from_points(q, quv), box_from_points(qu, qv));
+    return add_node(std::move(n), user);
+  }
+  int make_group(const std::vector<int>& kids, int kind, bool user) {  // group.rs:15-34
+    HNode n;
+    n.kind = kind;
+    n.box = box_empty();
+    for (int k : kids) {
+      n.box = box_union(n.box, nodes[k].box);
+      nodes[k].referenced = true;
+    }
+    n.kids = kids;
+    return add_node(std::move(n), user);
+  }
+  int make_box(const double* a, const double* b, int mat) {  // box_node.rs:15-74
+    double mn[3], mx[3];
+    for (int i = 0; i < 3; i++) { mn[i] = std::fmin(a[i], b[i]); mx[i] = std::fmax(a[i], b[i]); }
+    double dx[3] = {mx[0] - mn[0], 0.0, 0.0}, dy[3] = {0.0, mx[1] - mn[1], 0.0}, dz[3] = {0.0, 0.0, mx[2] - mn[2]};
+    double ndx[3] = {-dx[0], -dx[1], -dx[2]}, ndz[3] = {-dz[0], -dz[1], -dz[2]};
+    std::vector<int> faces;
+    double q0[3] = {mn[0], mn[1], mx[2]};
+    faces.push_back(make_quad(q0, dx, dy, mat, false));  // front
+    double q1[3] = {mx[0], mn[1], mx[2]};
+    faces.push_back(make_quad(q1, ndz, dy, mat, false));  // right
+    double q2[3] = {mx[0], mn[1], mn[2]};
+    faces.push_back(make_quad(q2, ndx, dy, mat, false));  // back
+    double q3[3] = {mn[0], mn[1], mn[2]};
+    faces.push_back(make_quad(q3, dz, dy, mat, false));  // left
+    double q4[3] = {mn[0], mx[1], mx[2]};
+    faces.push_back(make_quad(q4, dx, ndz, mat, false));  // top
+    double q5[3] = {mn[0], mn[1], mn[2]};
+    faces.push_back(make_quad(q5, dx, dz, mat, false));  // bottom
+    return make_group(faces, CHIP_NODE_BOX, true);
+  }
+  // bounding_volume_hierarchy.rs:16-46; items are host indices
+  int make_bvh(const std::vector<int>& items, bool user) {
+    Box6 span = box_empty();
+    for (int k : items) span = box_union(span, nodes[k].box);
+    int left, right;
+    if (items.empty()) {
+      left = make_group({}, CHIP_NODE_GROUP, false);
+      right = make_group({}, CHIP_NODE_GROUP, false);
+    } else if (items.size() == 1) {
+      left = right = items[0];
+    } else if (items.size() == 2) {
+      left = items[0];
+      right = items[1];
+    } else {
+      int axis = box_longest_axis(span);
+      std::vector<int> sorted = items;
+      // slice::sort_by is a stable sort; key = bbox.axis_interval(axis).min under total_cmp (bvh.rs:87-91)
+      std::stable_sort(sorted.begin(), sorted.end(),
+                       [&](int x, int y) { return total_less(nodes[x].box.v[2 * axis], nodes[y].box.v[2 * axis]); });
+      size_t mid = sorted.size() / 2;
+      left = make_bvh(std::vector<int>(sorted.begin(), sorted.begin() + mid), false);
+      right = make_bvh(std::vector<int>(sorted.begin() + mid, sorted.end()), false);
+    }
+    HNode n;
+    n.kind = CHIP_NODE_BVH;
+    n.c0 = left;
+    n.c1 = right;
+    n.box = box_union(nodes[left].box, nodes[right].box);
+    nodes[left].referenced = true;
+    nodes[right].referenced = true;
+    return add_node(std::move(n), user);
+  }
+  int make_translate(int child, const double* off) {  // translate.rs:15-22, aabb.rs:307-313 (no re-padding)
+    HNode n;
+    n.kind = CHIP_NODE_TRANSLATE;
+    n.c0 = child;
+    for (int i = 0; i < 3; i++) n.a[i] = off[i];
+    const Box6& cb = nodes[child].box;
+    for (int a = 0; a < 3; a++) { n.box.v[2 * a] = cb.v[2 * a] + off[a]; n.box.v[2 * a + 1] = cb.v[2 * a + 1] + off[a]; }
+    nodes[child].referenced = true;
+    return add_node(std::move(n), true);
+  }
+  int make_rotate(int child, const double* axis_in, double deg) {  // rotate.rs:19-79, 96-131
+    HNode n;
+    n.kind = CHIP_NODE_ROTATE;
+    n.c0 = child;
+    double radians = deg * (kPi / 180.0);
+    double s = std::sin(radians), c = std::cos(radians);
+    double al = std::sqrt(axis_in[0] * axis_in[0] + axis_in[1] * axis_in[1] + axis_in[2] * axis_in[2]);
+    double x = axis_in[0] / al, y = axis_in[1] / al, z = axis_in[2] / al;
+    double omc = 1.0 - c;
+    double* m = n.a;
+    m[0] = c + x * x * omc;     m[1] = x * y * omc - z * s; m[2] = x * z * omc + y * s;
+    m[3] = y * x * omc + z * s; m[4] = c + y * y * omc;     m[5] = y * z * omc - x * s;
+    m[6] = z * x * omc - y * s; m[7] = z * y * omc + x * s; m[8] = c + z * z * omc;
+    const Box6& ob = nodes[child].box;
+    double mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 2; j++)
+        for (int k = 0; k < 2; k++) {
+          double fi = (double)i, fj = (double)j, fk = (double)k;
+          double px = fi * ob.v[1] + (1.0 - fi) * ob.v[0];
+          double py = fj * ob.v[3] + (1.0 - fj) * ob.v[2];
+          double pz = fk * ob.v[5] + (1.0 - fk) * ob.v[4];
+          double rx = m[0] * px + m[1] * py + m[2] * pz;
+          double ry = m[3] * px + m[4] * py + m[5] * pz;
+          double rz = m[6] * px + m[7] * py + m[8] * pz;
+          mn[0] = std::fmin(mn[0], rx); mn[1] = std::fmin(mn[1], ry); mn[2] = std::fmin(mn[2], rz);
+          mx[0] = std::fmax(mx[0], rx); mx[1] = std::fmax(mx[1], ry); mx[2] = std::fmax(mx[2], rz);
+        }
+    n.box = box_from_points(mn, mx);
+    nodes[child].referenced = true;
+    return add_node(std::move(n), true);
+  }
+  int make_medium(int boundary, double density, int isotropic_mat) {  // constant_medium.rs:19-37, 82-84
+    HNode n;
+    n.kind = CHIP_NODE_MEDIUM;
+    n.c0 = boundary;
+    n.a[0] = -1.0 / density;
+    n.mat = isotropic_mat;
+    n.box = nodes[boundary].box;
+    nodes[boundary].referenced = true;
+    return add_node(std::move(n), true);
+  }
+
+  // CameraBuilder::build, camera.rs:126-182
+  void build_camera(const chip_camera_desc& b) {
+    cam_desc = b;
+    DCamera& c = cam;
+    uint32_t ih = (uint32_t)((double)b.image_width / b.aspect_ratio);
+    c.image_height = ih < 1 ? 1 : ih;
+    c.image_width = b.image_width;
+    c.sqrt_spp = (uint32_t)std::sqrt((double)b.samples_per_pixel);
+    c.pixel_samples_scale = 1.0 / (double)(c.sqrt_spp * c.sqrt_spp);
+    c.recip_sqrt_spp = 1.0 / (double)c.sqrt_spp;
+    double theta = b.vertical_fov * (kPi / 180.0);
+    double h = std::tan(theta / 2.0);
+    double viewport_height = 2.0 * h * b.focus_distance;
+    double viewport_width = viewport_height * ((double)c.image_width / (double)c.image_height);
+    auto sub = [](const double* p, const double* q, double* o) { for (int i = 0; i < 3; i++) o[i] = p[i] - q[i]; };
+    auto norm = [](double* p) {
+      double xs = p[0] * p[0], ys = p[1] * p[1], zs = p[2] * p[2];
+      double l = std::sqrt(xs + ys + zs);
+      for (int i = 0; i < 3; i++) p[i] = p[i] / l;
+    };
+    auto crossp = [](const double* p, const double* q, double* o) {
+      o[0] = p[1] * q[2] - p[2] * q[1];
+      o[1] = p[2] * q[0] - p[0] * q[2];
+      o[2] = p[0] * q[1] - p[1] * q[0];
+    };
+    double w[3], u[3], v[3];
+    sub(b.look_from, b.look_at, w);
+    norm(w);
+    crossp(b.up, w, u);
+    norm(u);
+    crossp(w, u, v);
+    double vu[3], vv[3];
+    for (int i = 0; i < 3; i++) {
+      c.center[i] = b.look_from[i];
+      vu[i] = u[i] * viewport_width;      // viewport_width * u
+      vv[i] = (-v[i]) * viewport_height;  // viewport_height * -v
+      c.du[i] = vu[i] / (double)c.image_width;
+      c.dv[i] = vv[i] / (double)c.image_height;
+    }
+    for (int i = 0; i < 3; i++) {
+      double upper_left = c.center[i] - (w[i] * b.focus_distance) - vu[i] / 2.0 - vv[i] / 2.0;
+      c.pixel00[i] = upper_left + (c.du[i] + c.dv[i]) * 0.5;
+    }
+    double defocus_radius = b.focus_distance * std::tan((b.defocus_angle / 2.0) * (kPi / 180.0));
+    for (int i = 0; i < 3; i++) {
+      c.disk_u[i] = u[i] * defocus_radius;
+      c.disk_v[i] = v[i] * defocus_radius;
+      c.background[i] = b.background[i];
+    }
+    c.max_depth = b.max_depth;
+    c.defocus_angle = b.defocus_angle;
+    has_camera = true;
+  }
+
+  // ---- flattening
+  struct Flattener {
+    const HostScene& H;
+    Flat& F;
+    explicit Flattener(const HostScene& h, Flat& f) : H(h), F(f) {}
+
+    void chain_of(nref_t x, std::vector<nref_t>& out) const {
+      out.clear();
+      if (x == NREF_NONE) return;
+      uint32_t first, n;
+      if (NREF_KIND(x) == NK_TRANSLATE) { first = F.translates[NREF_INDEX(x)].chain_first; n = F.translates[NREF_INDEX(x)].chain_len; }
+      else { first = F.rotates[NREF_INDEX(x)].chain_first; n = F.rotates[NREF_INDEX(x)].chain_len; }
+      out.assign(F.xchain.begin() + first, F.xchain.begin() + first + n);
+    }
+
+    nref_t emit_sphere(const HNode& n, nref_t xform, int leaf_id) {
+      DSphere s;
+      std::memset(&s, 0, sizeof(s));
+      for (int i = 0; i < 3; i++) { s.c[i] = n.a[i]; s.dc[i] = n.a[3 + i]; }
+      s.r = n.a[6];
+      s.mat = (uint32_t)n.mat;
+      s.xform = xform;
+      s.leaf_id = leaf_id;
+      F.spheres.push_back(s);
+      return NREF(NK_SPHERE, F.spheres.size() - 1);
+    }
+    nref_t emit_quad(const HNode& n, nref_t xform, int leaf_id) {
+      DQuad q;
+      std::memset(&q, 0, sizeof(q));
+      for (int i = 0; i < 3; i++) { q.q[i] = n.a[i]; q.u[i] = n.a[3 + i]; q.v[i] = n.a[6 + i]; q.n[i] = n.a[9 + i]; q.w[i] = n.a[12 + i]; }
+      q.d = n.a[15];
+      q.area = n.a[16];
+      q.mat = (uint32_t)n.mat;
+      q.xform = xform;
+      q.leaf_id = leaf_id;
+      F.quads.push_back(q);
+      return NREF(NK_QUAD, F.quads.size() - 1);
+    }
+
+    // h: host index; xform: innermost transform ancestor; in_boundary: inside a medium's boundary subtree;
+    // leaf_override: creation id reported for hits (a box reports its own id for its faces).
+    nref_t emit(int h, nref_t xform, bool in_boundary, int leaf_override) {
+      const HNode& n = H.nodes[h];
+      switch (n.kind) {
+        case CHIP_NODE_SPHERE: return emit_sphere(n, xform, leaf_override >= 0 ? leaf_override : n.id);
+        case CHIP_NODE_QUAD: return emit_quad(n, xform, leaf_override >= 0 ? leaf_override : n.id);
+        case CHIP_NODE_GROUP:
+        case CHIP_NODE_BOX: {
+          int lo = n.kind == CHIP_NODE_BOX ? n.id : leaf_override;
+          std::vector<nref_t> refs;
+          refs.reserve(n.kids.size());
+          for (int k : n.kids) refs.push_back(emit(k, xform, in_boundary, lo));
+          DGroup g;
+          g.first = (uint32_t)F.gchild.size();
+          g.count = (uint32_t)refs.size();
+          F.gchild.insert(F.gchild.end(), refs.begin(), refs.end());
+          F.groups.push_back(g);
+          return NREF(NK_GROUP, F.groups.size() - 1);
+        }
+        case CHIP_NODE_BVH: {
+          size_t idx = F.bvh.size();
+          F.bvh.push_back(DBvhNode{});
+          nref_t l = emit(n.c0, xform, in_boundary, leaf_override);
+          nref_t r = n.c1 == n.c0 ? l : emit(n.c1, xform, in_boundary, leaf_override);
+          DBvhNode& b = F.bvh[idx];
+          for (int i = 0; i < 6; i++) b.box[i] = n.box.v[i];
+          b.left = l;
+          b.right = r;
+          b.pad[0] = b.pad[1] = 0;
+          return NREF(NK_BVH, idx);
+        }
+        case CHIP_NODE_TRANSLATE:
+        case CHIP_NODE_ROTATE: {
+          std::vector<nref_t> chain;
+          chain_of(xform, chain);
+          nref_t self;
+          size_t idx;
+          if (n.kind == CHIP_NODE_TRANSLATE) {
+            idx = F.translates.size();
+            F.translates.push_back(DTranslate{});
+            self = NREF(NK_TRANSLATE, idx);
+          } else {
+            idx = F.rotates.size();
+            F.rotates.push_back(DRotate{});
+            self = NREF(NK_ROTATE, idx);
+          }
+          chain.push_back(self);
+          uint32_t cf = (uint32_t)F.xchain.size();
+          F.xchain.insert(F.xchain.end(), chain.begin(), chain.end());
+          if (n.kind == CHIP_NODE_TRANSLATE) {
+            DTranslate& t = F.translates[idx];
+            for (int i = 0; i < 3; i++) t.off[i] = n.a[i];
+            t.parent_xform = xform;
+            t.chain_first = cf;
+            t.chain_len = (uint32_t)chain.size();
+          } else {
+            DRotate& t = F.rotates[idx];
+            for (int i = 0; i < 9; i++) t.m[i] = n.a[i];
+            t.parent_xform = xform;
+            t.chain_first = cf;
+            t.chain_len = (uint32_t)chain.size();
+          }
+          nref_t c = emit(n.c0, self, in_boundary, leaf_override);
+          if (n.kind == CHIP_NODE_TRANSLATE) F.translates[idx].child = c;
+          else F.rotates[idx].child = c;
+          return self;
+        }
+        case CHIP_NODE_MEDIUM: {
+          if (in_boundary) throw std::runtime_error("a ConstantMedium inside another medium's boundary is not supported");
+          size_t idx = F.media.size();
+          F.media.push_back(DMedium{});
+          nref_t b = emit(n.c0, xform, true, -1);
+          DMedium& m = F.media[idx];
+          m.neg_inv_density = n.a[0];
+          m.boundary = b;
+          m.mat = (uint32_t)n.mat;
+          m.xform = xform;
+          m.leaf_id = n.id;
+          return NREF(NK_MEDIUM, idx);
+        }
+      }
+      throw std::runtime_error("unknown node kind");
+    }
+
+    void emit_light(int h) {
+      const HNode& n = H.nodes[h];
+      DLight L;
+      if (n.kind == CHIP_NODE_SPHERE) { L.kind = LK_SPHERE; L.index = NREF_INDEX(emit_sphere(n, NREF_NONE, n.id)); }
+      else if (n.kind == CHIP_NODE_QUAD) { L.kind = LK_QUAD; L.index = NREF_INDEX(emit_quad(n, NREF_NONE, n.id)); }
+      else if (n.kind == CHIP_NODE_GROUP) throw std::runtime_error("nested Group inside the lights group is not supported");
+      else { L.kind = LK_OTHER; L.index = 0; }  // Node::pdf_value / random defaults (object/mod.rs:59-65)
+      F.lights.push_back(L);
+    }
+  };
+
+  void flatten(Flat& F) const {
+    if (world < 0) throw std::runtime_error("scene has no world");
+    if (!has_camera) throw std::runtime_error("scene has no camera");
+    Flattener fl(*this, F);
+    F.root = fl.emit(handle[world], NREF_NONE, false, -1);
+    if (lights >= 0) {
+      F.has_lights = 1;
+      const HNode& L = nodes[handle[lights]];
+      if (L.kind == CHIP_NODE_GROUP) {
+        F.lights_is_group = 1;
+        for (int k : L.kids) fl.emit_light(k);
+      } else {
+        F.lights_is_group = 0;
+        fl.emit_light(handle[lights]);
+      }
+    }
+    if (F.bvh.size() >= (1u << 28) || F.spheres.size() >= (1u << 28) || F.quads.size() >= (1u << 28))
+      throw std::runtime_error("scene too large for 28-bit node indices");
+  }
+
+  // Preorder dump in the order the reference's tree would be walked.
+  void dump(int h, int32_t* kinds, int32_t* ids, double* boxes, size_t cap, size_t& count) const {
+    const HNode& n = nodes[h];
+    if (count < cap) {
+      kinds[count] = n.kind;
+      ids[count] = n.id;
+      for (int i = 0; i < 6; i++) boxes[6 * count + i] = n.box.v[i];
+    }
+    count++;
+    switch (n.kind) {
+      case CHIP_NODE_BVH:
+        dump(n.c0, kinds, ids, boxes, cap, count);
+        dump(n.c1, kinds, ids, boxes, cap, count);
+        break;
+      case CHIP_NODE_GROUP:
+      case CHIP_NODE_BOX:
+        for (int k : n.kids) dump(k, kinds, ids, boxes, cap, count);
+        break;
+      case CHIP_NODE_TRANSLATE:
+      case CHIP_NODE_ROTATE:
+      case CHIP_NODE_MEDIUM: dump(n.c0, kinds, ids, boxes, cap, count); break;
+      default: break;
+    }
+  }
+};
+
+}  // namespace chip
