@@ -5,5 +5,5 @@ The product is `libcaustic_hip.so` (C ABI in include/caustic_hip.h, sources in c
 The directory name contains a hyphen, so import it with
 `importlib.import_module("rust-raytracer_amd")`.
 """
-from . import bindings, scenes  # noqa: F401
+from . import bindings, distributed, scenes  # noqa: F401
 from .bindings import CausticError, load_gpu, gpu_device_count  # noqa: F401

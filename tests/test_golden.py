@@ -1,0 +1,58 @@
+"""Committed golden vectors (tests/golden/golden_v1.npz, produced by tests/golden/make_golden.py from
+the oracle): the oracle must keep reproducing them on the CPU, and the GPU path must hit the same
+numbers through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = ["random_spheres", "final", "cornell_box", "cornell_box_smoke", "three_spheres", "perlin_spheres"]
+KW = dict(width=32, spp=4, depth=8)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+
+
+def _check(sc, g, name, exact_image, sum_dtype):
+    hits = sc.trace_rays(g[name + "/o"], g[name + "/d"], g[name + "/time"], seed=9)
+    assert np.array_equal(hits["hit"], g[name + "/hit"].astype(np.int32))
+    m = hits["hit"] == 1
+    assert np.array_equal(hits["leaf_id"], g[name + "/leaf_id"])
+    rel = np.abs(hits["t"][m] - g[name + "/t"][m]) / np.abs(g[name + "/t"][m])
+    assert rel.max() <= 1e-5
+    assert np.abs(hits["normal"][m] - g[name + "/normal"][m]).max() <= 1e-5
+    assert np.abs(np.stack([hits["u"], hits["v"]], axis=1)[m] - g[name + "/uv"][m]).max() <= 1e-5
+    img, _, st = sc.render_frame(seed=21, sum_dtype=sum_dtype)
+    want = g[name + "/image_sum"]
+    if exact_image:
+        assert np.array_equal(img, want)
+        assert st["segments"] == int(g[name + "/segments"][0])
+    else:
+        bad = np.abs(img.astype(np.float64) - want) > 1e-3 * (1.0 + np.abs(want))
+        assert bad.mean() < 5e-3
+        assert abs(st["segments"] - int(g[name + "/segments"][0])) <= 4
+    kinds, ids, boxes = sc.dump_tree()
+    assert np.array_equal(kinds, g[name + "/tree_kinds"].astype(np.int32))
+    assert np.array_equal(ids, g[name + "/tree_ids"])
+    assert np.array_equal(boxes.view(np.uint64), g[name + "/tree_boxes"].view(np.uint64))
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_oracle_reproduces_golden(pkg, oracle, golden, name):
+    sc = pkg.scenes.build(oracle, name, **KW)
+    _check(sc, golden, name, exact_image=False, sum_dtype=np.float64)
+    # hits are pure +,-,*,/,sqrt in a fixed order: bit-identical on any IEEE machine
+    hits = sc.trace_rays(golden[name + "/o"], golden[name + "/d"], golden[name + "/time"], seed=9)
+    m = hits["hit"] == 1
+    if name not in ("final", "cornell_box_smoke"):  # media use log(): libm-dependent last bits
+        assert np.array_equal(hits["t"][m].view(np.uint64), golden[name + "/t"][m].view(np.uint64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCENES)
+def test_gpu_reproduces_golden(pkg, gpu, golden, name):
+    sc = pkg.scenes.build(gpu, name, **KW)
+    _check(sc, golden, name, exact_image=False, sum_dtype=np.float32)

@@ -1,0 +1,125 @@
+"""CPU-side checks of libcaustic_hip.so: the library loads and exports every symbol the header declares,
+and the host logic (scene graph, bounding boxes, BVH layout, derived camera, argument checking) agrees
+with the oracle.  No kernel is launched here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ALL_SCENES = ["random_spheres", "final", "cornell_box", "cornell_box_smoke", "three_spheres", "checkered_spheres", "earth", "perlin_spheres", "quads", "lighted_sphere"]
+
+
+def test_library_exports_every_declared_symbol(gpu_lib):
+    text = open(os.path.join(ROOT, "include", "caustic_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(chip_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(gpu_lib.lib, n), f"{n} declared in caustic_hip.h but not exported"
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_bvh_layout_and_boxes_equal_oracle(pkg, gpu_lib, oracle, name):
+    """bounding_volume_hierarchy.rs:16-46: same topology, same leaf order, bit-identical boxes."""
+    sg = gpu_lib.new_scene()
+    so = oracle.new_scene()
+    pkg.scenes.SCENES[name](sg, width=64, spp=4, depth=4)
+    pkg.scenes.SCENES[name](so, width=64, spp=4, depth=4)
+    kg, ig, bg = sg.dump_tree()
+    ko, io, bo = so.dump_tree()
+    assert np.array_equal(kg, ko)
+    assert np.array_equal(ig, io)
+    assert np.array_equal(bg.view(np.uint64), bo.view(np.uint64))
+    assert np.array_equal(sg.camera_derived().view(np.uint64), so.camera_derived().view(np.uint64))
+    assert sg.image_size() == so.image_size() and sg.sqrt_spp() == so.sqrt_spp()
+
+
+def test_bvh_small_counts(gpu_lib, oracle):
+    """len 0 -> two empty groups, 1 -> (n0, n0), 2 -> (n0, n1) unsorted, 3 -> sorted split at len/2."""
+    def tree(be, centers):
+        sc = be.new_scene()
+        m = sc.lambertian_color(0.5, 0.5, 0.5)
+        ids = [sc.sphere(c, 0.5, m) for c in centers]
+        sc.set_world(sc.bvh(ids))
+        return sc.dump_tree()
+
+    for centers in ([], [(0, 0, 0)], [(5, 0, 0), (-5, 0, 0)], [(5, 0, 0), (-5, 0, 0), (0, 0, 0)], [(0, 0, 3), (0, 0, 1), (0, 0, 2), (0, 0, 0), (0, 0, 1)]):
+        kg, ig, bg = tree(gpu_lib, centers)
+        ko, io, bo = tree(oracle, centers)
+        assert np.array_equal(kg, ko) and np.array_equal(ig, io)
+        assert np.array_equal(bg.view(np.uint64), bo.view(np.uint64))
+    k, i, b = tree(gpu_lib, [])
+    assert k.tolist() == [0, 3, 3]  # BVH over two empty Groups
+    k, i, b = tree(gpu_lib, [(0, 0, 0)])
+    assert k.tolist() == [0, 1, 1] and i.tolist() == [1, 0, 0]  # the single node is both children
+    k, i, b = tree(gpu_lib, [(5, 0, 0), (-5, 0, 0)])
+    assert i.tolist() == [2, 0, 1]  # two nodes keep their given order
+    k, i, b = tree(gpu_lib, [(5, 0, 0), (-5, 0, 0), (0, 0, 0)])
+    # sorted by x-min: ids 1,2,0 ; mid = 1 -> left BVH{1} (1 twice), right BVH{2,0}
+    assert k.tolist() == [0, 0, 1, 1, 0, 1, 1] and i.tolist() == [3, -1, 1, 1, -1, 2, 0]
+    # stable sort keeps equal keys in input order: z-min keys 2.5,.5,1.5,-.5,.5 -> ids 3,1,4,2,0
+    k, i, b = tree(gpu_lib, [(0, 0, 3), (0, 0, 1), (0, 0, 2), (0, 0, 0), (0, 0, 1)])
+    leaves = [x for x, kk in zip(i.tolist(), k.tolist()) if kk == 1]
+    assert leaves == [3, 1, 4, 4, 2, 0]  # {3,1} | {4} (stored twice) + {2,0}
+
+
+def test_moving_sphere_and_rotate_boxes(gpu_lib, oracle):
+    def tree(be):
+        sc = be.new_scene()
+        m = sc.lambertian_color(0.5, 0.5, 0.5)
+        s = sc.sphere((1, 2, 3), 0.5, m, direction=(0.0, 0.4, -2.0))
+        bx = sc.box((0, 0, 0), (1, 2, 3), m)
+        r = sc.rotate(bx, (1.0, 2.0, -0.5), 33.0)
+        t = sc.translate(r, (10.0, -3.0, 0.25))
+        q = sc.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), m)  # flat in z: padded by 1e-4
+        sc.set_world(sc.bvh([s, t, q]))
+        return sc.dump_tree()
+
+    kg, ig, bg = tree(gpu_lib)
+    ko, io, bo = tree(oracle)
+    assert np.array_equal(kg, ko) and np.array_equal(ig, io)
+    assert np.array_equal(bg.view(np.uint64), bo.view(np.uint64))
+    sphere_box = bg[list(ig).index(0)]
+    np.testing.assert_allclose(sphere_box, [0.5, 1.5, 1.5, 2.9, 0.5, 3.5])
+    quad_box = bg[list(ig).index(4)]
+    assert quad_box[4] == -0.00005 and quad_box[5] == 0.00005
+
+
+def test_host_argument_errors(pkg, gpu_lib):
+    sc = gpu_lib.new_scene()
+    with pytest.raises(pkg.CausticError):
+        sc.lambertian_tex(3)
+    with pytest.raises(pkg.CausticError):
+        sc.sphere((0, 0, 0), 1.0, 0)
+    m = sc.lambertian_color(0.1, 0.2, 0.3)
+    s = sc.sphere((0, 0, 0), 1.0, m)
+    q = sc.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), m)
+    with pytest.raises(pkg.CausticError):
+        sc.sphere_set_direction(q, (0, 1, 0))  # not a sphere
+    g = sc.group([s, q])
+    with pytest.raises(pkg.CausticError):
+        sc.sphere_set_direction(s, (0, 1, 0))  # already referenced (Rust: mutated before Arc::new)
+    with pytest.raises(pkg.CausticError):
+        sc.group([s, 99])
+    with pytest.raises(pkg.CausticError):
+        sc.set_world(99)
+    with pytest.raises(pkg.CausticError):
+        sc.tex_checker(1.0, 0, 77)
+    with pytest.raises(pkg.CausticError):
+        sc.set_camera(image_width=0)
+    with pytest.raises(pkg.CausticError):
+        sc.render_frame()  # not committed
+    sc.set_world(g)
+    assert "scene" in gpu_lib.last_error() or gpu_lib.last_error()
+
+
+def test_image_height_rule(gpu_lib, oracle):
+    """camera.rs:127-128: height = (width / aspect) as u32, at least 1."""
+    for be in (gpu_lib, oracle):
+        for width, aspect, want in [(1920, 16.0 / 9.0, 1080), (400, 16.0 / 9.0, 225), (300, 16.0 / 9.0, 168), (10, 100.0, 1), (800, 1.0, 800)]:
+            sc = be.new_scene()
+            sc.set_camera(image_width=width, aspect_ratio=aspect)
+            assert sc.image_size() == (width, want)
