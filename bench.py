@@ -171,6 +171,11 @@ def main():
                 "segments_per_path": seg / (sum(s["paths"] for s in stats)) if stats else None,
                 "trace_share_of_device_time": ms_trace / sum(s["ms_total"] for s in stats) if stats else None,
             },
+            "device_ms_per_step": {
+                "render_call": sum(s["ms_total"] for s in stats) / args.steps,
+                "traversal": ms_trace / args.steps,
+                "bin_and_shade": sum(s["ms_shade"] for s in stats) / args.steps,
+            },
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width, args.depth, args.seed)

@@ -17,7 +17,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-GPU_LIB_PATH = os.path.join(_HERE, "libcaustic_hip.so")
+# CAUSTIC_HIP_LIB selects another build of the same library (used to A/B kernel variants).
+GPU_LIB_PATH = os.environ.get("CAUSTIC_HIP_LIB") or os.path.join(_HERE, "libcaustic_hip.so")
 
 
 class CameraDesc(C.Structure):

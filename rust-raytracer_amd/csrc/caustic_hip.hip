@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -92,6 +93,14 @@ struct chip_scene {
   }
 };
 
+// Smallest traversal variant that covers the node families present in the flattened scene.
+static uint32_t scene_features(const Flat& F) {
+  if (!F.media.empty()) return TF_QUADS | TF_XFORM | TF_MEDIA;
+  if (!F.translates.empty() || !F.rotates.empty()) return TF_QUADS | TF_XFORM;
+  if (!F.quads.empty() || !F.groups.empty()) return TF_QUADS;
+  return 0;
+}
+
 static const uint32_t kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 
 static size_t pool_capacity_default() {
@@ -109,7 +118,7 @@ static int ensure_pool(chip_scene* s) {
   size_t cap = pool_capacity_default();
   if (!s->pool_ready) {
     HIP_TRY(s->p_ray.alloc(7 * cap));
-    HIP_TRY(s->p_hit.alloc(9 * cap));
+    HIP_TRY(s->p_hit.alloc(cap));
     HIP_TRY(s->p_st.alloc(12 * cap));
     HIP_TRY(s->p_sample.alloc(3 * cap));
     HIP_TRY(s->p_hinfo.alloc(cap));
@@ -178,7 +187,9 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
   const DScene& S = s->dscene;
   const DCamera& cam = s->host.cam;
   const bool time_kernels = (o->flags & CHIP_RENDER_TIME_KERNELS) != 0;
-  const bool has_media = !s->flat.media.empty();  // scenes without ConstantMedium run the leaner traversal
+  const uint32_t feat = scene_features(s->flat);
+  uint32_t mat_mask = 0;
+  for (const DMaterial& m : s->host.materials) mat_mask |= 1u << m.kind;  // scenes lacking a node family run a leaner traversal variant
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0));
   HIP_TRY(hipEventCreate(&ev1));
@@ -219,16 +230,22 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       for (uint32_t bounce = 0; bounce < cam.max_depth; bounce++) {
         uint32_t grid = grid_for(live_upper);
         if (time_kernels) (void)hipEventRecord(new_event(), stream);
-        if (has_media) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce);
-        else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce);
+        switch (feat) {
+          case 0: hipLaunchKernelGGL(k_extend<0>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce); break;
+          case TF_QUADS: hipLaunchKernelGGL(k_extend<TF_QUADS>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce); break;
+          case TF_QUADS | TF_XFORM: hipLaunchKernelGGL(k_extend<TF_QUADS | TF_XFORM>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce); break;
+          default: hipLaunchKernelGGL(k_extend<TF_QUADS | TF_XFORM | TF_MEDIA>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce); break;
+        }
         if (time_kernels) (void)hipEventRecord(new_event(), stream);
         n_trace_launches++;
-        launch_shade<MK_LAMBERTIAN>(S, P, B, bounce, grid, stream);
-        launch_shade<MK_METAL>(S, P, B, bounce, grid, stream);
-        launch_shade<MK_DIELECTRIC>(S, P, B, bounce, grid, stream);
-        launch_shade<MK_DIFFUSE_LIGHT>(S, P, B, bounce, grid, stream);
-        launch_shade<MK_ISOTROPIC>(S, P, B, bounce, grid, stream);
-        launch_shade<MK_EMPTY>(S, P, B, bounce, grid, stream);
+        hipLaunchKernelGGL(k_bin, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, bounce, (uint32_t)((feat & TF_MEDIA) != 0));
+        // only the material kinds the scene contains can have queue entries
+        if (mat_mask & (1u << MK_LAMBERTIAN)) launch_shade<MK_LAMBERTIAN>(S, P, B, bounce, grid, stream);
+        if (mat_mask & (1u << MK_METAL)) launch_shade<MK_METAL>(S, P, B, bounce, grid, stream);
+        if (mat_mask & (1u << MK_DIELECTRIC)) launch_shade<MK_DIELECTRIC>(S, P, B, bounce, grid, stream);
+        if (mat_mask & (1u << MK_DIFFUSE_LIGHT)) launch_shade<MK_DIFFUSE_LIGHT>(S, P, B, bounce, grid, stream);
+        if (mat_mask & (1u << MK_ISOTROPIC)) launch_shade<MK_ISOTROPIC>(S, P, B, bounce, grid, stream);
+        if (mat_mask & (1u << MK_EMPTY)) launch_shade<MK_EMPTY>(S, P, B, bounce, grid, stream);
         if (time_kernels) (void)hipEventRecord(new_event(), stream);
         // every few bounces learn how many paths are still alive (stops the loop early)
         if (bounce + 1 < cam.max_depth && (bounce % 4) == 3) {
@@ -310,6 +327,8 @@ static int add_mat(chip_scene* s, uint32_t kind, int tex, double p0, double p1, 
   m.kind = kind;
   m.tex = tex;
   m.p[0] = p0; m.p[1] = p1; m.p[2] = p2; m.p[3] = p3;
+  m.flags = 0;
+  m.pad = 0;
   s->host.materials.push_back(m);
   s->committed = false;
   return (int)s->host.materials.size() - 1;
@@ -542,6 +561,19 @@ int chip_commit(chip_scene* s) {
   HIP_TRY(s->d_rotates.upload(F.rotates));
   HIP_TRY(s->d_media.upload(F.media));
   HIP_TRY(s->d_xchain.upload(F.xchain));
+  // a material needs (u, v) only when an image texture is reachable from its texture (checker sub-textures included)
+  {
+    const std::vector<DTexture>& T = s->host.textures;
+    std::vector<int> uv(T.size(), -1);
+    std::function<bool(int, int)> needs = [&](int t, int depth) -> bool {
+      if (t < 0 || (size_t)t >= T.size() || depth > 64) return true;
+      if (uv[t] >= 0) return uv[t] != 0;
+      bool r = T[t].kind == TK_IMAGE || (T[t].kind == TK_CHECKER && (needs((int)T[t].a, depth + 1) || needs((int)T[t].b, depth + 1)));
+      uv[t] = r ? 1 : 0;
+      return r;
+    };
+    for (DMaterial& m : s->host.materials) m.flags = (m.tex >= 0 && needs(m.tex, 0)) ? MF_NEEDS_UV : 0u;
+  }
   HIP_TRY(s->d_materials.upload(s->host.materials));
   HIP_TRY(s->d_textures.upload(s->host.textures));
   HIP_TRY(s->d_perlins.upload(s->host.perlins));
@@ -664,12 +696,16 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
       if ((e = hipMemcpy(d_t.p, tm, n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
     }
     if ((e = hipMemset(s->pool.errflag, 0, 4 * sizeof(uint32_t))) != hipSuccess) break;
-    if (!s->flat.media.empty())
-      hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, s->dscene, s->pool, (uint32_t)seed,
-                         (uint32_t)(seed >> 32), (uint32_t)n, d_o.p, d_d.p, tm ? d_t.p : nullptr, d_out.p);
-    else
-      hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, s->dscene, s->pool, (uint32_t)seed,
-                         (uint32_t)(seed >> 32), (uint32_t)n, d_o.p, d_d.p, tm ? d_t.p : nullptr, d_out.p);
+#define CHIP_TRACE(FEAT)                                                                                                         \
+  hipLaunchKernelGGL(k_trace_rays<FEAT>, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, s->dscene, s->pool, (uint32_t)seed, \
+                     (uint32_t)(seed >> 32), (uint32_t)n, d_o.p, d_d.p, tm ? d_t.p : nullptr, d_out.p)
+    switch (scene_features(s->flat)) {
+      case 0: CHIP_TRACE(0); break;
+      case TF_QUADS: CHIP_TRACE(TF_QUADS); break;
+      case TF_QUADS | TF_XFORM: CHIP_TRACE(TF_QUADS | TF_XFORM); break;
+      default: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA); break;
+    }
+#undef CHIP_TRACE
     if ((e = hipGetLastError()) != hipSuccess) break;
     if ((e = hipDeviceSynchronize()) != hipSuccess) break;
     if ((e = hipMemcpy(out, d_out.p, n * sizeof(DHitOut), hipMemcpyDeviceToHost)) != hipSuccess) break;

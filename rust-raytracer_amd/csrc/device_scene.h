@@ -78,10 +78,13 @@ struct alignas(8) DMedium {
 };
 
 enum : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_DIFFUSE_LIGHT = 3, MK_ISOTROPIC = 4, MK_EMPTY = 5, MK_COUNT = 6 };
+enum : uint32_t { MF_NEEDS_UV = 1 };  // the material's texture tree contains an image texture (reads u, v)
 struct alignas(8) DMaterial {
   uint32_t kind;
   int32_t tex;  // Lambertian / DiffuseLight / Isotropic texture id
   double p[4];  // Metal: albedo rgb, fuzz; Dielectric: refraction index
+  uint32_t flags;
+  uint32_t pad;
 };
 
 enum : uint32_t { TK_SOLID = 0, TK_CHECKER = 1, TK_IMAGE = 2, TK_NOISE = 3, TK_TURBULENCE = 4 };

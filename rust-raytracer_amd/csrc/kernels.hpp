@@ -13,22 +13,26 @@
 #include "device_scene.h"
 
 #define CHIP_BLOCK 256
-#define CHIP_STACK_LDS 24  // per-lane short stack entries kept in LDS
-#define CHIP_STACK_OVF 40  // further entries spill to a per-thread global slab
+#define CHIP_STACK_LDS 16  // per-lane short stack entries kept in LDS
+#define CHIP_STACK_OVF 48  // further entries spill to a per-thread global slab
+#ifndef CHIP_REFILL_THRESH
+#define CHIP_REFILL_THRESH 1  // a traversing wave refills its idle lanes once fewer than this many are busy
+#endif
+#define CHIP_TILE 2048  // queue entries a block compacts locally before one global append
 #define CHIP_PI 3.14159265358979323846
 #define CHIP_BIG 1e30f
 
 // ------------------------------------------------------------------ path pool (SoA, stride = capacity)
 struct PathPool {
   double* ray;      // [7][cap]  origin xyz, direction xyz, time
-  double* hit;      // [9][cap]  t, pt xyz, normal xyz, u, v
+  double* hit;      // [cap]     t of the closest hit of the current segment
   float* st;        // [12][cap] a rgb, b rgb, lo rgb, hi rgb of  x -> clamp(a + b x, lo, hi)
-  uint32_t* hinfo;  // [cap]     material id | front_face << 31
+  uint32_t* hinfo;  // [cap]     node reference of the closest hit (NREF_NONE = miss)
   uint32_t* draw;   // [cap]     uniforms already consumed in the current bounce
   float* sample;    // [3][cap]  finished sample radiance
   uint32_t* q_live[2];  // [cap] live path slots, ping-pong per bounce
   uint32_t* q_mat;      // [MK_COUNT][cap] per-material-kind shade queues
-  uint32_t* counters;   // [max_depth+1][8]: [b][0] live entering bounce b, [b][1..6] material queue sizes
+  uint32_t* counters;   // [max_depth+2][8]: [b][0] live entering bounce b, [b][1..6] material queue sizes, [b][7] live-queue cursor
   uint32_t* errflag;    // [4]: [0] traversal stack overflow
   unsigned long long* stats;  // [4]: segments, bvh visits, prim tests, spare
   uint32_t* ovf;        // [threads][CHIP_STACK_OVF] traversal stack spill
@@ -180,7 +184,7 @@ __device__ inline uint32_t st_pop(TravStack& s, int base) {
 // aabb.rs:195-228.  The per-axis early return is folded into one final test: the
 // running interval only ever narrows and NaN candidates are never stored, so
 // "max <= min after some axis" holds at the end iff it held after that axis.
-__device__ inline bool aabb_hit(const double* b, const TravRay& r, double tmin, double tmax) {
+__device__ __noinline__ bool aabb_hit_chain(const double* b, V3 o, V3 inv, double tmin, double tmax) {
 #define CHIP_SLAB(lo, hi, o, inv)            \
   {                                          \
     double t0 = ((lo) - (o)) * (inv);        \
@@ -193,10 +197,28 @@ __device__ inline bool aabb_hit(const double* b, const TravRay& r, double tmin, 
       if (t0 < tmax) tmax = t0;              \
     }                                        \
   }
-  CHIP_SLAB(b[0], b[1], r.o.x, r.inv.x)
-  CHIP_SLAB(b[2], b[3], r.o.y, r.inv.y)
-  CHIP_SLAB(b[4], b[5], r.o.z, r.inv.z)
+  CHIP_SLAB(b[0], b[1], o.x, inv.x)
+  CHIP_SLAB(b[2], b[3], o.y, inv.y)
+  CHIP_SLAB(b[4], b[5], o.z, inv.z)
 #undef CHIP_SLAB
+  return !(tmax <= tmin);
+}
+// Same decision with min/max instructions: for ordered t0, t1 the compare chain above is
+// tmin = max(tmin, min(t0,t1)), tmax = min(tmax, max(t0,t1)).  When a slab product is NaN
+// (0 * inf: zero direction component with the origin on a slab plane) the chain's
+// "comparison false => no update" behaviour differs from min/max, so those lanes take the chain.
+__device__ inline bool aabb_hit(const double* b, const TravRay& r, double tmin, double tmax) {
+  double t0x = (b[0] - r.o.x) * r.inv.x, t1x = (b[1] - r.o.x) * r.inv.x;
+  double t0y = (b[2] - r.o.y) * r.inv.y, t1y = (b[3] - r.o.y) * r.inv.y;
+  double t0z = (b[4] - r.o.z) * r.inv.z, t1z = (b[5] - r.o.z) * r.inv.z;
+  if (__builtin_expect(__builtin_isunordered(t0x, t1x) || __builtin_isunordered(t0y, t1y) || __builtin_isunordered(t0z, t1z), 0))
+    return aabb_hit_chain(b, r.o, r.inv, tmin, tmax);
+  tmin = fmax(tmin, fmin(t0x, t1x));
+  tmax = fmin(tmax, fmax(t0x, t1x));
+  tmin = fmax(tmin, fmin(t0y, t1y));
+  tmax = fmin(tmax, fmax(t0y, t1y));
+  tmin = fmax(tmin, fmin(t0z, t1z));
+  tmax = fmin(tmax, fmax(t0z, t1z));
   return !(tmax <= tmin);
 }
 
@@ -259,42 +281,53 @@ __device__ inline void ray_to_space(const DScene& S, nref_t x, V3 wo, V3 wd, V3&
   for (uint32_t i = 0; i < n; i++) apply_xform(S, S.xchain[first + i], o, d);
 }
 
-// Closest hit below `start` for the ray in r, over (tmin, best_t]; best_t doubles as
-// the shrinking interval maximum of bvh.rs:66-70 / group.rs:47-52.  MEDIA = the subtree
-// may contain ConstantMedium nodes (a medium's boundary subtree may not).
-template <bool MEDIA>
-__device__ void traverse(const DScene& S, nref_t start, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng, TravStack& st,
-                         TravCounters& cnt);
+// Scene features a traversal instantiation handles (scenes lacking a feature run a leaner variant).
+enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4 };  // quads & groups | Translate & Rotate | ConstantMedium
 
+// Closest hit below `start` for the ray in r, over (tmin, best_t]; best_t doubles as
+// the shrinking interval maximum of bvh.rs:66-70 / group.rs:47-52.
+// `node` is the traversal cursor: on entry the node to visit, on return NREF_NONE when the subtree
+// is exhausted.  With YIELD the loop also returns (cursor and stack intact, to be resumed) as soon as
+// fewer than CHIP_REFILL_THRESH lanes of the wave are still traversing, so the caller can hand the
+// idle lanes new rays.
+template <uint32_t F, bool YIELD>
+__device__ void traverse(const DScene& S, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng, TravStack& st,
+                         const int base, TravCounters& cnt, bool may_yield = true);
+
+// A medium's boundary subtree (constant_medium.rs:42-45) is traversed on the same stack; it may hold
+// anything except another medium.
 __device__ __noinline__ void traverse_boundary(const DScene& S, nref_t start, TravRay& r, double tmin, double& best_t, nref_t& best,
                                                Rng& rng, TravStack& st, TravCounters& cnt) {
-  traverse<false>(S, start, r, tmin, best_t, best, rng, st, cnt);
+  nref_t node = start;
+  traverse<TF_QUADS | TF_XFORM, false>(S, node, r, tmin, best_t, best, rng, st, st.sp, cnt);
 }
 
-template <bool MEDIA>
-__device__ void traverse(const DScene& S, nref_t start, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng, TravStack& st,
-                         TravCounters& cnt) {
-  const int base = st.sp;
-  nref_t node = start;
-  while (node != NREF_NONE) {
-    uint32_t kind = NREF_KIND(node), idx = NREF_INDEX(node);
-    if (kind == NK_BVH) {
-      const DBvhNode& n = S.bvh[idx];
+template <uint32_t F, bool YIELD>
+__device__ void traverse(const DScene& S, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng, TravStack& st,
+                         const int base, TravCounters& cnt, bool may_yield) {
+  for (;;) {
+    // BVH descent (bvh.rs:58-76): test the node's own box over (tmin, best_t); left first, right deferred.
+    while (NREF_KIND(node) == NK_BVH) {
+      const DBvhNode& n = S.bvh[NREF_INDEX(node)];
       cnt.bvh++;
       if (aabb_hit(n.box, r, tmin, best_t)) {
         st_push(st, n.right);
         node = n.left;
-        continue;
+      } else {
+        node = st_pop(st, base);
       }
-    } else if (kind == NK_SPHERE) {
+    }
+    if (node == NREF_NONE) break;
+    const uint32_t kind = NREF_KIND(node), idx = NREF_INDEX(node);
+    if (kind == NK_SPHERE) {
       double t;
       cnt.prim++;
       if (sphere_hit(S.spheres[idx], r, tmin, best_t, t)) { best_t = t; best = node; }
-    } else if (kind == NK_QUAD) {
+    } else if ((F & TF_QUADS) && kind == NK_QUAD) {
       double t, al, be;
       cnt.prim++;
       if (quad_hit(S.quads[idx], r, tmin, best_t, t, al, be)) { best_t = t; best = node; }
-    } else if (kind == NK_GROUP || kind == NK_GROUP_CONT) {
+    } else if ((F & TF_QUADS) && (kind == NK_GROUP || kind == NK_GROUP_CONT)) {
       // group.rs:44-54: children in order, each over the shrinking interval.  Primitive
       // children are tested inline; any other child is descended into, leaving a
       // (position, continuation) pair on the stack.
@@ -323,13 +356,13 @@ __device__ void traverse(const DScene& S, nref_t start, TravRay& r, double tmin,
         }
       }
       if (descend != NREF_NONE) { node = descend; continue; }
-    } else if (kind == NK_TRANSLATE) {
+    } else if ((F & TF_XFORM) && kind == NK_TRANSLATE) {
       const DTranslate& t = S.translates[idx];
       st_push(st, NREF(NK_EXIT_TRANSLATE, idx));
       r.o = r.o - ld3(t.off);
       node = t.child;
       continue;
-    } else if (kind == NK_ROTATE) {
+    } else if ((F & TF_XFORM) && kind == NK_ROTATE) {
       const DRotate& t = S.rotates[idx];
       st_push(st, NREF(NK_EXIT_ROTATE, idx));
       r.o = mat_mulT(t.m, r.o);
@@ -337,11 +370,11 @@ __device__ void traverse(const DScene& S, nref_t start, TravRay& r, double tmin,
       ray_set_inv(r);
       node = t.child;
       continue;
-    } else if (kind == NK_EXIT_TRANSLATE || kind == NK_EXIT_ROTATE) {
+    } else if ((F & TF_XFORM) && (kind == NK_EXIT_TRANSLATE || kind == NK_EXIT_ROTATE)) {
       nref_t px = kind == NK_EXIT_TRANSLATE ? S.translates[idx].parent_xform : S.rotates[idx].parent_xform;
       ray_to_space(S, px, r.wo, r.wd, r.o, r.d);
       ray_set_inv(r);
-    } else if (MEDIA && kind == NK_MEDIUM) {
+    } else if ((F & TF_MEDIA) && kind == NK_MEDIUM) {
       // constant_medium.rs:41-80
       const DMedium m = S.media[idx];
       double t1 = INFINITY, t2 = INFINITY;
@@ -366,6 +399,7 @@ __device__ void traverse(const DScene& S, nref_t start, TravRay& r, double tmin,
       }
     }
     node = st_pop(st, base);
+    if (YIELD && may_yield && __popcll(__ballot(1)) < CHIP_REFILL_THRESH) break;
   }
 }
 
@@ -389,22 +423,29 @@ __device__ inline void sphere_uv(V3 p, double& u, double& v) {
 // the node's space, the record there (sphere.rs:122-134, quad.rs:159-181,
 // constant_medium.rs:70-79), then carry it back out through the enclosing
 // Translate / Rotate nodes (translate.rs:34, rotate.rs:145-146).
-__device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo, V3 wd, double time, HitOut& h) {
+// want_uv = the material's texture reads (u, v); the sphere's acos / atan2 are skipped otherwise.
+template <uint32_t F>
+__device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo, V3 wd, double time, HitOut& h, bool want_uv = true) {
   uint32_t kind = NREF_KIND(leaf), idx = NREF_INDEX(leaf);
-  nref_t x = kind == NK_SPHERE ? S.spheres[idx].xform : (kind == NK_QUAD ? S.quads[idx].xform : S.media[idx].xform);
-  V3 o, d;
-  ray_to_space(S, x, wo, wd, o, d);
+  nref_t x = NREF_NONE;
+  V3 o = wo, d = wd;
+  if (F & TF_XFORM) {
+    x = kind == NK_SPHERE ? S.spheres[idx].xform : (kind == NK_QUAD ? S.quads[idx].xform : S.media[idx].xform);
+    ray_to_space(S, x, wo, wd, o, d);
+  }
   h.pt = o + (t * d);
   if (kind == NK_SPHERE) {
     const DSphere& s = S.spheres[idx];
     V3 center = ld3(s.c) + (time * ld3(s.dc));
     V3 outward = (h.pt - center) / s.r;
-    sphere_uv(outward, h.u, h.v);
+    h.u = 0.0;
+    h.v = 0.0;
+    if (want_uv) sphere_uv(outward, h.u, h.v);
     h.front = dot(d, outward) < 0.0;
     h.n = h.front ? outward : -outward;
     h.mat = s.mat;
     h.leaf_id = s.leaf_id;
-  } else if (kind == NK_QUAD) {
+  } else if ((F & TF_QUADS) && kind == NK_QUAD) {
     const DQuad& q = S.quads[idx];
     V3 planar = h.pt - ld3(q.q);
     V3 w = ld3(q.w);
@@ -415,7 +456,7 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
     h.n = h.front ? n : -n;
     h.mat = q.mat;
     h.leaf_id = q.leaf_id;
-  } else {
+  } else if (F & TF_MEDIA) {
     const DMedium& m = S.media[idx];
     h.n = mk(1.0, 0.0, 0.0);
     h.u = 0.0;
@@ -424,16 +465,18 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
     h.mat = m.mat;
     h.leaf_id = m.leaf_id;
   }
-  uint32_t first, n;
-  xform_chain(S, x, first, n);
-  for (uint32_t i = n; i > 0; i--) {
-    nref_t xf = S.xchain[first + i - 1];
-    if (NREF_KIND(xf) == NK_TRANSLATE) {
-      h.pt = h.pt + ld3(S.translates[NREF_INDEX(xf)].off);
-    } else {
-      const double* m = S.rotates[NREF_INDEX(xf)].m;
-      h.pt = mat_mul(m, h.pt);
-      h.n = mat_mul(m, h.n);
+  if (F & TF_XFORM) {
+    uint32_t first, n;
+    xform_chain(S, x, first, n);
+    for (uint32_t i = n; i > 0; i--) {
+      nref_t xf = S.xchain[first + i - 1];
+      if (NREF_KIND(xf) == NK_TRANSLATE) {
+        h.pt = h.pt + ld3(S.translates[NREF_INDEX(xf)].off);
+      } else {
+        const double* m = S.rotates[NREF_INDEX(xf)].m;
+        h.pt = mat_mul(m, h.pt);
+        h.n = mat_mul(m, h.n);
+      }
     }
   }
 }
@@ -676,62 +719,94 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_raygen(DScene S, PathPool P, Bat
   if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[0] = B.n_paths;
 }
 
-// One world.hit (camera.rs:264) per live path: traversal, HitRecord, binning by material kind.
-template <bool MEDIA>
-__global__ void __launch_bounds__(CHIP_BLOCK) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce) {
+// One world.hit (camera.rs:264) per live path: closest-hit traversal; stores (t, node) per path.
+// Waves are persistent: lanes pull path slots from the bounce's live queue through a shared cursor
+// (counters[bounce][7]) and a wave refills its idle lanes whenever too few are still traversing, so
+// short rays do not leave lanes idle while long rays finish.
+#ifndef CHIP_EXTEND_WAVES
+#define CHIP_EXTEND_WAVES 4
+#endif
+template <uint32_t F>
+__global__ void __launch_bounds__(CHIP_BLOCK, (F & TF_MEDIA) ? 1 : ((F & TF_XFORM) ? 2 : CHIP_EXTEND_WAVES)) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce) {
   __shared__ uint32_t lds_stack[CHIP_STACK_LDS * CHIP_BLOCK];
   const uint32_t* q_in = P.q_live[bounce & 1];
   uint32_t* ctr = P.counters + (size_t)bounce * 8;
   const uint32_t n_live = ctr[0];
+  uint32_t* cursor = &ctr[7];
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = __lane_id();
   TravStack st;
   st.lds = lds_stack + threadIdx.x;
   st.ovf = P.ovf + (size_t)gtid * CHIP_STACK_OVF;
   st.overflow = 0;
+  st.sp = 0;
   TravCounters cnt{0, 0};
   uint32_t nseg = 0;
   const size_t cap = P.cap;
-  // whole waves iterate together so the ballots in queue_push see uniform control flow
-  const uint32_t n_round = (n_live + 63u) & ~63u;
-  for (uint32_t i = gtid; i < n_round; i += gridDim.x * blockDim.x) {
-    const bool active = i < n_live;
-    uint32_t slot = 0, kind = MK_COUNT;
-    if (active) {
-      slot = q_in[i];
-      TravRay r;
-      r.wo = mk(P.ray[0 * cap + slot], P.ray[1 * cap + slot], P.ray[2 * cap + slot]);
-      r.wd = mk(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
-      r.time = P.ray[6 * cap + slot];
-      r.o = r.wo; r.d = r.wd;
-      ray_set_inv(r);
-      uint32_t x, y, pixel, stratum;
-      slot_to_path(B, S.cam, slot, x, y, pixel, stratum);
-      Rng rng;
-      rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, 0);
-      double best_t = INFINITY;
-      nref_t best = NREF_NONE;
-      st.sp = 0;
-      traverse<MEDIA>(S, S.root, r, 0.001, best_t, best, rng, st, cnt);
+  bool has = false;  // this lane holds a ray (traversing or finished)
+  uint32_t slot = 0;
+  TravRay r;
+  r.wo = r.wd = r.o = r.d = r.inv = mk(0, 0, 0);
+  r.time = 0;
+  double best_t = INFINITY;
+  nref_t best = NREF_NONE, node = NREF_NONE;
+  Rng rng;
+  rng.init(B.seed_lo, B.seed_hi, 0, 0, bounce, 0);
+  // chunk of the live queue a wave reserves at a time: large enough to keep the shared cursor cold,
+  // small enough to leave every wave of the grid some work
+  const uint32_t n_waves = gridDim.x * (CHIP_BLOCK / 64);
+  uint32_t chunk = (n_live / (n_waves * 4u)) & ~63u;
+  chunk = chunk < 64u ? 64u : (chunk > 2048u ? 2048u : chunk);
+  uint32_t w_next = 0, w_end = 0;  // wave-uniform
+  bool exhausted = false;
+  for (;;) {
+    // 1. lanes whose traversal finished store (t, node); the HitRecord is rebuilt where it is consumed
+    if (has && node == NREF_NONE) {
       nseg++;
-      if (best == NREF_NONE) {
-        Affine f;
-        affine_load(P, slot, f);
-        float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
-        finish_path(P, slot, f, bg);
-      } else {
-        HitOut h;
-        reconstruct(S, best, best_t, r.wo, r.wd, r.time, h);
-        P.hit[0 * cap + slot] = best_t;
-        P.hit[1 * cap + slot] = h.pt.x; P.hit[2 * cap + slot] = h.pt.y; P.hit[3 * cap + slot] = h.pt.z;
-        P.hit[4 * cap + slot] = h.n.x; P.hit[5 * cap + slot] = h.n.y; P.hit[6 * cap + slot] = h.n.z;
-        P.hit[7 * cap + slot] = h.u; P.hit[8 * cap + slot] = h.v;
-        P.hinfo[slot] = h.mat | (h.front ? 0x80000000u : 0u);
-        P.draw[slot] = rng.draw;
-        kind = S.materials[h.mat].kind;
+      P.hit[slot] = best_t;
+      P.hinfo[slot] = best;
+      if (F & TF_MEDIA) P.draw[slot] = rng.draw;
+      has = false;
+    }
+    // 2. idle lanes take the next entries of the wave's current chunk of the live queue; a new chunk is
+    //    reserved from the shared cursor (one atomic per chunk) when the current one is used up
+    {
+      const unsigned long long need = __ballot(!has);
+      if (need) {
+        if (w_next >= w_end && !exhausted) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(cursor, chunk);
+          base = __shfl(base, 0);
+          w_next = base;
+          w_end = min(base + chunk, n_live);
+          if (base >= n_live) { exhausted = true; w_end = w_next; }
+        }
+        const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
+        const uint32_t avail = w_end - w_next;
+        if (!has && rank < avail) {
+          slot = q_in[w_next + rank];
+          r.wo = mk(P.ray[0 * cap + slot], P.ray[1 * cap + slot], P.ray[2 * cap + slot]);
+          r.wd = mk(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
+          r.time = P.ray[6 * cap + slot];
+          r.o = r.wo; r.d = r.wd;
+          ray_set_inv(r);
+          if (F & TF_MEDIA) {
+            uint32_t x, y, pixel, stratum;
+            slot_to_path(B, S.cam, slot, x, y, pixel, stratum);
+            rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, 0);
+          }
+          best_t = INFINITY;
+          best = NREF_NONE;
+          node = S.root;
+          st.sp = 0;
+          has = true;
+        }
+        w_next += min((uint32_t)__popcll(need), avail);
       }
     }
-#pragma unroll
-    for (uint32_t k = 0; k < MK_COUNT; k++) queue_push(P.q_mat + (size_t)k * cap, &ctr[1 + k], kind == k, slot);
+    if (!__any(has) && exhausted) break;
+    // 3. traverse until the rays are done or too few lanes are still busy
+    if (has) traverse<F, true>(S, node, r, 0.001, best_t, best, rng, st, 0, cnt, !(exhausted && w_next >= w_end));
   }
   if (st.overflow) atomicOr(&P.errflag[0], 1u);
   // per-wave reduction of the traversal counters
@@ -740,10 +815,68 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_extend(DScene S, PathPool P, Bat
     cnt.prim += __shfl_down(cnt.prim, off);
     nseg += __shfl_down(nseg, off);
   }
-  if (__lane_id() == 0 && nseg) {
+  if (lane == 0 && nseg) {
     atomicAdd(&P.stats[0], (unsigned long long)nseg);
     atomicAdd(&P.stats[1], (unsigned long long)cnt.bvh);
     atomicAdd(&P.stats[2], (unsigned long long)cnt.prim);
+  }
+}
+
+// Entries a block compacts per global append: up to CHIP_TILE, but small enough that a short queue
+// still spreads over the whole grid.
+__device__ inline uint32_t tile_size(uint32_t n, uint32_t blocks) {
+  uint32_t t = (n / blocks) & ~(uint32_t)(CHIP_BLOCK - 1);
+  return t < CHIP_BLOCK ? CHIP_BLOCK : (t > CHIP_TILE ? CHIP_TILE : t);
+}
+
+// Material of a hit node (sphere.rs:132, quad.rs:179, constant_medium.rs:78).
+__device__ inline uint32_t node_material(const DScene& S, nref_t leaf) {
+  uint32_t kind = NREF_KIND(leaf), idx = NREF_INDEX(leaf);
+  return kind == NK_SPHERE ? S.spheres[idx].mat : (kind == NK_QUAD ? S.quads[idx].mat : S.media[idx].mat);
+}
+
+// After traversal: misses return the background (camera.rs:264-266) and finish; hits are binned into
+// the shade queue of their material kind.  A block bins a tile of CHIP_TILE entries in LDS and reserves
+// its output ranges with one global atomic per material kind.
+__global__ void __launch_bounds__(CHIP_BLOCK) k_bin(DScene S, PathPool P, uint32_t bounce, uint32_t has_media) {
+  const uint32_t* q_in = P.q_live[bounce & 1];
+  uint32_t* ctr = P.counters + (size_t)bounce * 8;
+  const uint32_t n_live = ctr[0];
+  const size_t cap = P.cap;
+  __shared__ uint32_t s_slot[CHIP_TILE];
+  __shared__ uint16_t s_rank[CHIP_TILE];
+  __shared__ uint8_t s_kind[CHIP_TILE];
+  __shared__ uint32_t s_cnt[MK_COUNT], s_base[MK_COUNT];
+  const uint32_t tile = tile_size(n_live, gridDim.x);
+  for (uint32_t tile0 = blockIdx.x * tile; tile0 < n_live; tile0 += gridDim.x * tile) {
+    if (threadIdx.x < MK_COUNT) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tile_n = min(tile, n_live - tile0);
+    for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
+      const uint32_t slot = q_in[tile0 + k];
+      const nref_t best = P.hinfo[slot];
+      uint32_t kind = MK_COUNT;
+      if (best == NREF_NONE) {
+        Affine f;
+        affine_load(P, slot, f);
+        float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
+        finish_path(P, slot, f, bg);
+      } else {
+        kind = S.materials[node_material(S, best)].kind;
+        if (!has_media) P.draw[slot] = 0u;
+        s_rank[k] = (uint16_t)atomicAdd(&s_cnt[kind], 1u);
+      }
+      s_slot[k] = slot;
+      s_kind[k] = (uint8_t)kind;
+    }
+    __syncthreads();
+    if (threadIdx.x < MK_COUNT) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&ctr[1 + threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
+      const uint32_t kind = s_kind[k];
+      if (kind < MK_COUNT) P.q_mat[(size_t)kind * cap + s_base[kind] + s_rank[k]] = s_slot[k];
+    }
+    __syncthreads();
   }
 }
 
@@ -758,23 +891,36 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, Batc
   uint32_t* q_out = P.q_live[(bounce + 1) & 1];
   const size_t cap = P.cap;
   const bool last_bounce = bounce + 1 >= S.cam.max_depth;
-  const uint32_t n_round = (n + 63u) & ~63u;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+  // A block takes tiles of CHIP_TILE queue entries; surviving paths are compacted in LDS and appended
+  // to the next bounce's live queue with one global atomic per tile.
+  __shared__ uint32_t s_pend[CHIP_TILE];
+  __shared__ uint32_t s_cnt, s_base;
+  const uint32_t tile = tile_size(n, gridDim.x);
+  for (uint32_t tile0 = blockIdx.x * tile; tile0 < n; tile0 += gridDim.x * tile) {
+   if (threadIdx.x == 0) s_cnt = 0;
+   __syncthreads();
+   const uint32_t tile_end = min(tile0 + tile, n);
+   for (uint32_t i = tile0 + threadIdx.x; i < tile_end; i += CHIP_BLOCK) {
     bool cont = false;
     uint32_t slot = 0;
-    if (i < n) {
+    {
       slot = q[i];
       Affine f;
       affine_load(P, slot, f);
-      const uint32_t hinfo = P.hinfo[slot];
-      const bool front = hinfo >> 31;
-      const DMaterial& M = S.materials[hinfo & 0x7FFFFFFFu];
-      V3 pt = mk(P.hit[1 * cap + slot], P.hit[2 * cap + slot], P.hit[3 * cap + slot]);
+      // HitRecord of the segment's closest hit (object/mod.rs:31-51), rebuilt from (ray, t, node)
+      const nref_t leaf = P.hinfo[slot];
+      const DMaterial& M = S.materials[node_material(S, leaf)];
+      V3 ro = mk(P.ray[0 * cap + slot], P.ray[1 * cap + slot], P.ray[2 * cap + slot]);
+      V3 rd = mk(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
+      HitOut hrec;
+      reconstruct<TF_QUADS | TF_XFORM | TF_MEDIA>(S, leaf, P.hit[slot], ro, rd, P.ray[6 * cap + slot], hrec, (M.flags & MF_NEEDS_UV) != 0);
+      const bool front = hrec.front;
+      const V3 pt = hrec.pt;
       if (KIND == MK_DIFFUSE_LIGHT) {
         // diffuse_light.rs:28-43: no scatter; emits on the front face only
         float x[3] = {0.f, 0.f, 0.f};
         if (front) {
-          V3 e = tex_value(S, M.tex, P.hit[7 * cap + slot], P.hit[8 * cap + slot], pt);
+          V3 e = tex_value(S, M.tex, hrec.u, hrec.v, pt);
           x[0] = (float)e.x; x[1] = (float)e.y; x[2] = (float)e.z;
         }
         finish_path(P, slot, f, x);
@@ -782,8 +928,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, Batc
         float x[3] = {0.f, 0.f, 0.f};  // empty.rs:18-27 + default emitted
         finish_path(P, slot, f, x);
       } else {
-        V3 nrm = mk(P.hit[4 * cap + slot], P.hit[5 * cap + slot], P.hit[6 * cap + slot]);
-        V3 rd = mk(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
+        const V3 nrm = hrec.n;
         uint32_t x_, y_, pixel, stratum;
         slot_to_path(B, S.cam, slot, x_, y_, pixel, stratum);
         Rng rng;
@@ -816,7 +961,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, Batc
           w[0] = 1.f; w[1] = 1.f; w[2] = 1.f;
         } else {
           // Lambertian (lambertian.rs:29-49) / Isotropic (isotropic.rs:29-44): PDF branch, camera.rs:278-305
-          V3 atten = tex_value(S, M.tex, P.hit[7 * cap + slot], P.hit[8 * cap + slot], pt);
+          V3 atten = tex_value(S, M.tex, hrec.u, hrec.v, pt);
           bool use_light = false;
           if (S.has_lights) use_light = rng.next() < 0.5;  // mixture.rs:26-32
           Onb uvw(nrm);                                    // cosine.rs:10-14 (unused for Isotropic)
@@ -863,7 +1008,17 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, Batc
         }
       }
     }
-    if (KIND != MK_DIFFUSE_LIGHT && KIND != MK_EMPTY) queue_push(q_out, &ctr_next[0], cont, slot);
+    if (KIND != MK_DIFFUSE_LIGHT && KIND != MK_EMPTY) {
+      if (cont) s_pend[atomicAdd(&s_cnt, 1u)] = slot;
+    }
+   }
+   if (KIND != MK_DIFFUSE_LIGHT && KIND != MK_EMPTY) {
+     __syncthreads();
+     if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&ctr_next[0], s_cnt) : 0u;
+     __syncthreads();
+     for (uint32_t k = threadIdx.x; k < s_cnt; k += CHIP_BLOCK) q_out[s_base + k] = s_pend[k];
+   }
+   __syncthreads();
   }
 }
 
@@ -904,7 +1059,7 @@ struct DHitOut {
   double t, pt[3], normal[3], u, v;
   int32_t hit, leaf_id, front_face, material_kind;
 };
-template <bool MEDIA>
+template <uint32_t F>
 __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P, uint32_t seed_lo, uint32_t seed_hi, uint32_t n,
                                                            const double* o, const double* d, const double* tm, DHitOut* out) {
   __shared__ uint32_t lds_stack[CHIP_STACK_LDS * CHIP_BLOCK];
@@ -926,14 +1081,15 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P,
     double best_t = INFINITY;
     nref_t best = NREF_NONE;
     st.sp = 0;
-    traverse<MEDIA>(S, S.root, r, 0.001, best_t, best, rng, st, cnt);
+    nref_t node = S.root;
+    traverse<F, false>(S, node, r, 0.001, best_t, best, rng, st, 0, cnt);
     DHitOut h;
     h.t = 0; h.u = 0; h.v = 0;
     for (int k = 0; k < 3; k++) { h.pt[k] = 0; h.normal[k] = 0; }
     h.hit = 0; h.leaf_id = -1; h.front_face = 0; h.material_kind = -1;
     if (best != NREF_NONE) {
       HitOut ho;
-      reconstruct(S, best, best_t, r.wo, r.wd, r.time, ho);
+      reconstruct<F>(S, best, best_t, r.wo, r.wd, r.time, ho);
       h.hit = 1;
       h.t = best_t;
       h.pt[0] = ho.pt.x; h.pt[1] = ho.pt.y; h.pt[2] = ho.pt.z;
