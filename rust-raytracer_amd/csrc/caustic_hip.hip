@@ -53,6 +53,7 @@ struct chip_scene {
   HostScene host;
   bool committed = false;
   int device = 0;
+  int n_cus = 256;
   Flat flat;
   DevBuf<DBvhNode> d_bvh;
   DevBuf<DSphere> d_spheres;
@@ -101,6 +102,7 @@ static uint32_t scene_features(const Flat& F) {
   return 0;
 }
 
+static const uint32_t kMaxGridBlocksDef = 2048;
 static const uint32_t kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 
 static size_t pool_capacity_default() {
@@ -174,6 +176,60 @@ static int plan_render(chip_scene* s, const chip_render_opts* o, RenderPlan& pl)
   return 0;
 }
 
+// Traversal launch: picks the variant for the scene's node families and, when the scene has a BVH,
+// the LDS-cached form (one persistent block per CU; top of the BVH and leading spheres in LDS).
+struct ExtendPlan {
+  bool cache;
+  CacheDesc cd;
+  uint32_t block, lds_bytes;
+};
+static const uint32_t kLdsBytes = 160 * 1024;
+static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat) {
+  ExtendPlan p;
+  const char* e = getenv("CHIP_NO_LDS_CACHE");
+  p.cache = !s->flat.bvh.empty() && !(e && *e == '1');
+  if (p.cache) {
+    p.block = (feat & TF_MEDIA) ? 512 : 1024;
+    p.cd.stack_entries = 12;
+    uint32_t stack_bytes = p.cd.stack_entries * 4 * p.block;
+    uint32_t budget = (kLdsBytes - stack_bytes) / 64;
+    p.cd.n_bvh = (uint32_t)std::min<size_t>(s->flat.bvh.size(), budget);
+    p.cd.n_sph = (uint32_t)std::min<size_t>(s->flat.spheres.size(), budget - p.cd.n_bvh);
+    p.lds_bytes = 64 * (p.cd.n_bvh + p.cd.n_sph) + stack_bytes;
+  } else {
+    p.block = CHIP_BLOCK;
+    p.cd.stack_entries = CHIP_STACK_LDS;
+    p.cd.n_bvh = p.cd.n_sph = 0;
+    p.lds_bytes = CHIP_STACK_LDS * 4 * CHIP_BLOCK;
+  }
+  return p;
+}
+template <uint32_t F, bool CACHE>
+static void launch_extend_t(const chip_scene* s, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_extend<F, CACHE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    attr_set = true;
+  }
+  uint32_t blocks = (n_live_upper + p.block - 1) / p.block;
+  uint32_t max_blocks = CACHE ? (uint32_t)s->n_cus : kMaxGridBlocksDef;
+  blocks = std::max(1u, std::min(blocks, max_blocks));
+  hipLaunchKernelGGL((k_extend<F, CACHE>), dim3(blocks), dim3(p.block), p.lds_bytes, st, s->dscene, s->pool, B, bounce, p.cd);
+}
+static void launch_extend(const chip_scene* s, uint32_t feat, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce) {
+  const ExtendPlan p = plan_extend(s, feat);
+#define CHIP_EXT(FEAT)                                                                 \
+  if (p.cache) launch_extend_t<FEAT, true>(s, p, n_live_upper, st, B, bounce);         \
+  else launch_extend_t<FEAT, false>(s, p, n_live_upper, st, B, bounce)
+  switch (feat) {
+    case 0: CHIP_EXT(0); break;
+    case TF_QUADS: CHIP_EXT(TF_QUADS); break;
+    case TF_QUADS | TF_XFORM: CHIP_EXT(TF_QUADS | TF_XFORM); break;
+    default: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA); break;
+  }
+#undef CHIP_EXT
+}
+
 template <uint32_t K>
 static void launch_shade(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, uint32_t grid, hipStream_t st) {
   hipLaunchKernelGGL(k_shade<K>, dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
@@ -230,12 +286,7 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       for (uint32_t bounce = 0; bounce < cam.max_depth; bounce++) {
         uint32_t grid = grid_for(live_upper);
         if (time_kernels) (void)hipEventRecord(new_event(), stream);
-        switch (feat) {
-          case 0: hipLaunchKernelGGL(k_extend<0>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce); break;
-          case TF_QUADS: hipLaunchKernelGGL(k_extend<TF_QUADS>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce); break;
-          case TF_QUADS | TF_XFORM: hipLaunchKernelGGL(k_extend<TF_QUADS | TF_XFORM>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce); break;
-          default: hipLaunchKernelGGL(k_extend<TF_QUADS | TF_XFORM | TF_MEDIA>, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, B, bounce); break;
-        }
+        launch_extend(s, feat, live_upper, stream, B, bounce);
         if (time_kernels) (void)hipEventRecord(new_event(), stream);
         n_trace_launches++;
         hipLaunchKernelGGL(k_bin, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, bounce, (uint32_t)((feat & TF_MEDIA) != 0));
@@ -552,6 +603,11 @@ int chip_commit(chip_scene* s) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   s->device = dev;
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
   HIP_TRY(s->d_bvh.upload(F.bvh));
   HIP_TRY(s->d_spheres.upload(F.spheres));
   HIP_TRY(s->d_quads.upload(F.quads));

@@ -157,34 +157,104 @@ struct Onb {  // utils/orthonormal_basis.rs:57-68,95-97
 struct TravRay {
   V3 wo, wd;        // world-space ray (camera.rs:264 passes it to world.hit)
   V3 o, d, inv;     // ray in the current node's space and 1/d (aabb.rs:202)
+  double dd;        // direction.length_squared() of d (sphere.rs:102)
   double time;
 };
+// The traversal kernel's dynamic LDS: [scene cache records][per-lane stacks].  Declared at file scope so
+// that device functions index it directly and the compiler emits ds_read / ds_write (a pointer to it
+// stored in a struct decays to a generic pointer and is accessed with flat loads).
+extern __shared__ uint4 g_lds[];
+// Volatile LDS-address-space view of g_lds for the cache reads: keeps them ds_read_b128 (without it the
+// compiler merges the "cached / not cached" branches into one generic-pointer load).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) u32x4_t* lds_cv4_t;
+typedef __attribute__((address_space(3))) uint32_t* lds_u32_t;
+__device__ inline uint4 lds_read4(uint32_t i) {
+  lds_cv4_t p = (lds_cv4_t)g_lds;
+  u32x4_t t = p[i];
+  uint4 v;
+  v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+  return v;
+}
+
 struct TravStack {
-  uint32_t* lds;  // this lane's column of the block's LDS stack (stride CHIP_BLOCK)
+  lds_u32_t lds;  // this lane's column of the block's LDS stack
   uint32_t* ovf;  // this thread's global spill slab
   int sp;
   uint32_t overflow;
+  int lds_cap;      // entries kept in LDS
+  uint32_t shift;   // log2 of the LDS words between consecutive entries of one lane (= threads per block)
+};
+// Read-only copy of the hottest scene records in LDS: the first n_bvh BVH nodes (the tables are in
+// breadth-first order, so these are the top of the tree) and the first n_sph spheres.  Each 64-byte
+// record is split into four 16-byte components stored in separate arrays (component k of record i at
+// [k * cap + i]), which spreads the lanes of a wave over the LDS banks.
+struct NodeCache {
+  uint32_t bvh_off, sph_off;  // first uint4 of the BVH / sphere component arrays in g_lds
+  uint32_t n_bvh, n_sph;      // records cached
+  uint32_t cap_bvh, cap_sph;  // array strides (records)
 };
 struct TravCounters {
   uint32_t bvh, prim;
 };
 
 __device__ inline void st_push(TravStack& s, uint32_t v) {
-  if (s.sp < CHIP_STACK_LDS) s.lds[s.sp * CHIP_BLOCK] = v;
-  else if (s.sp < CHIP_STACK_LDS + CHIP_STACK_OVF) s.ovf[s.sp - CHIP_STACK_LDS] = v;
+  if (s.sp < s.lds_cap) s.lds[s.sp << s.shift] = v;
+  else if (s.sp < s.lds_cap + CHIP_STACK_OVF) s.ovf[s.sp - s.lds_cap] = v;
   else { s.overflow = 1; return; }
   s.sp++;
 }
 __device__ inline uint32_t st_pop(TravStack& s, int base) {
   if (s.sp <= base) return NREF_NONE;
   s.sp--;
-  return s.sp < CHIP_STACK_LDS ? s.lds[s.sp * CHIP_BLOCK] : s.ovf[s.sp - CHIP_STACK_LDS];
+  return s.sp < s.lds_cap ? s.lds[s.sp << s.shift] : s.ovf[s.sp - s.lds_cap];
+}
+
+// Register images of the two records the traversal reads most.
+struct BvhRec {
+  double box[6];
+  nref_t left, right;
+};
+struct SphereRec {
+  double c[3], dc[3], r;
+};
+__device__ inline double u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+template <bool CACHE>
+__device__ inline void load_bvh(const DScene& S, const NodeCache& C, uint32_t idx, BvhRec& n) {
+  uint4 a, b, c, d;
+  if (CACHE && idx < C.n_bvh) {
+    const uint32_t i = C.bvh_off + idx;
+    a = lds_read4(i); b = lds_read4(i + C.cap_bvh); c = lds_read4(i + 2 * C.cap_bvh); d = lds_read4(i + 3 * C.cap_bvh);
+  } else {
+    const uint4* p = reinterpret_cast<const uint4*>(S.bvh + idx);
+    a = p[0]; b = p[1]; c = p[2]; d = p[3];
+  }
+  n.box[0] = u2d(a.x, a.y); n.box[1] = u2d(a.z, a.w);
+  n.box[2] = u2d(b.x, b.y); n.box[3] = u2d(b.z, b.w);
+  n.box[4] = u2d(c.x, c.y); n.box[5] = u2d(c.z, c.w);
+  n.left = d.x; n.right = d.y;
+}
+template <bool CACHE>
+__device__ inline void load_sphere(const DScene& S, const NodeCache& C, uint32_t idx, SphereRec& n) {
+  uint4 a, b, c, d;
+  if (CACHE && idx < C.n_sph) {
+    const uint32_t i = C.sph_off + idx;
+    a = lds_read4(i); b = lds_read4(i + C.cap_sph); c = lds_read4(i + 2 * C.cap_sph); d = lds_read4(i + 3 * C.cap_sph);
+  } else {
+    const uint4* p = reinterpret_cast<const uint4*>(S.spheres + idx);
+    a = p[0]; b = p[1]; c = p[2]; d = p[3];
+  }
+  n.c[0] = u2d(a.x, a.y); n.c[1] = u2d(a.z, a.w);
+  n.c[2] = u2d(b.x, b.y); n.dc[0] = u2d(b.z, b.w);
+  n.dc[1] = u2d(c.x, c.y); n.dc[2] = u2d(c.z, c.w);
+  n.r = u2d(d.x, d.y);
 }
 
 // aabb.rs:195-228.  The per-axis early return is folded into one final test: the
 // running interval only ever narrows and NaN candidates are never stored, so
 // "max <= min after some axis" holds at the end iff it held after that axis.
-__device__ __noinline__ bool aabb_hit_chain(const double* b, V3 o, V3 inv, double tmin, double tmax) {
+__device__ __noinline__ bool aabb_hit_chain(double b0, double b1, double b2, double b3, double b4, double b5, V3 o, V3 inv, double tmin,
+                                             double tmax) {
 #define CHIP_SLAB(lo, hi, o, inv)            \
   {                                          \
     double t0 = ((lo) - (o)) * (inv);        \
@@ -197,9 +267,9 @@ __device__ __noinline__ bool aabb_hit_chain(const double* b, V3 o, V3 inv, doubl
       if (t0 < tmax) tmax = t0;              \
     }                                        \
   }
-  CHIP_SLAB(b[0], b[1], o.x, inv.x)
-  CHIP_SLAB(b[2], b[3], o.y, inv.y)
-  CHIP_SLAB(b[4], b[5], o.z, inv.z)
+  CHIP_SLAB(b0, b1, o.x, inv.x)
+  CHIP_SLAB(b2, b3, o.y, inv.y)
+  CHIP_SLAB(b4, b5, o.z, inv.z)
 #undef CHIP_SLAB
   return !(tmax <= tmin);
 }
@@ -207,26 +277,39 @@ __device__ __noinline__ bool aabb_hit_chain(const double* b, V3 o, V3 inv, doubl
 // tmin = max(tmin, min(t0,t1)), tmax = min(tmax, max(t0,t1)).  When a slab product is NaN
 // (0 * inf: zero direction component with the origin on a slab plane) the chain's
 // "comparison false => no update" behaviour differs from min/max, so those lanes take the chain.
+// v_min_f64 / v_max_f64 without the operand canonicalisation the compiler adds to fmin / fmax (it cannot
+// prove the operands are not signalling NaNs); used only where the operands are known to be ordered.
+__device__ inline double vmin_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline double vmax_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ inline bool aabb_hit(const double* b, const TravRay& r, double tmin, double tmax) {
   double t0x = (b[0] - r.o.x) * r.inv.x, t1x = (b[1] - r.o.x) * r.inv.x;
   double t0y = (b[2] - r.o.y) * r.inv.y, t1y = (b[3] - r.o.y) * r.inv.y;
   double t0z = (b[4] - r.o.z) * r.inv.z, t1z = (b[5] - r.o.z) * r.inv.z;
   if (__builtin_expect(__builtin_isunordered(t0x, t1x) || __builtin_isunordered(t0y, t1y) || __builtin_isunordered(t0z, t1z), 0))
-    return aabb_hit_chain(b, r.o, r.inv, tmin, tmax);
-  tmin = fmax(tmin, fmin(t0x, t1x));
-  tmax = fmin(tmax, fmax(t0x, t1x));
-  tmin = fmax(tmin, fmin(t0y, t1y));
-  tmax = fmin(tmax, fmax(t0y, t1y));
-  tmin = fmax(tmin, fmin(t0z, t1z));
-  tmax = fmin(tmax, fmax(t0z, t1z));
+    return aabb_hit_chain(b[0], b[1], b[2], b[3], b[4], b[5], r.o, r.inv, tmin, tmax);
+  tmin = vmax_f64(tmin, vmin_f64(t0x, t1x));
+  tmax = vmin_f64(tmax, vmax_f64(t0x, t1x));
+  tmin = vmax_f64(tmin, vmin_f64(t0y, t1y));
+  tmax = vmin_f64(tmax, vmax_f64(t0y, t1y));
+  tmin = vmax_f64(tmin, vmin_f64(t0z, t1z));
+  tmax = vmin_f64(tmax, vmax_f64(t0z, t1z));
   return !(tmax <= tmin);
 }
 
 // sphere.rs:99-121: nearest root strictly inside (tmin, tmax)
-__device__ inline bool sphere_hit(const DSphere& s, const TravRay& r, double tmin, double tmax, double& t_out) {
+template <typename SphereT>
+__device__ inline bool sphere_hit(const SphereT& s, const TravRay& r, double tmin, double tmax, double& t_out) {
   V3 center = ld3(s.c) + (r.time * ld3(s.dc));
   V3 oc = center - r.o;
-  double a = len2(r.d);
+  double a = r.dd;
   double h = dot(r.d, oc);
   double c = len2(oc) - s.r * s.r;
   double disc = h * h - a * c;
@@ -257,7 +340,10 @@ __device__ inline bool quad_hit(const DQuad& q, const TravRay& r, double tmin, d
   return true;
 }
 
-__device__ inline void ray_set_inv(TravRay& r) { r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z); }
+__device__ inline void ray_set_inv(TravRay& r) {
+  r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+  r.dd = len2(r.d);
+}
 // translate.rs:28 / rotate.rs:137-138
 __device__ inline void apply_xform(const DScene& S, nref_t x, V3& o, V3& d) {
   if (NREF_KIND(x) == NK_TRANSLATE) {
@@ -290,25 +376,27 @@ enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4 };  // quads & groups
 // is exhausted.  With YIELD the loop also returns (cursor and stack intact, to be resumed) as soon as
 // fewer than CHIP_REFILL_THRESH lanes of the wave are still traversing, so the caller can hand the
 // idle lanes new rays.
-template <uint32_t F, bool YIELD>
-__device__ void traverse(const DScene& S, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng, TravStack& st,
-                         const int base, TravCounters& cnt, bool may_yield = true);
+template <uint32_t F, bool YIELD, bool CACHE>
+__device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng,
+                         TravStack& st, const int base, TravCounters& cnt, bool may_yield = true);
 
 // A medium's boundary subtree (constant_medium.rs:42-45) is traversed on the same stack; it may hold
 // anything except another medium.
 __device__ __noinline__ void traverse_boundary(const DScene& S, nref_t start, TravRay& r, double tmin, double& best_t, nref_t& best,
                                                Rng& rng, TravStack& st, TravCounters& cnt) {
   nref_t node = start;
-  traverse<TF_QUADS | TF_XFORM, false>(S, node, r, tmin, best_t, best, rng, st, st.sp, cnt);
+  NodeCache none{0, 0, 0, 0, 0, 0};
+  traverse<TF_QUADS | TF_XFORM, false, false>(S, none, node, r, tmin, best_t, best, rng, st, st.sp, cnt);
 }
 
-template <uint32_t F, bool YIELD>
-__device__ void traverse(const DScene& S, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng, TravStack& st,
-                         const int base, TravCounters& cnt, bool may_yield) {
+template <uint32_t F, bool YIELD, bool CACHE>
+__device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng,
+                         TravStack& st, const int base, TravCounters& cnt, bool may_yield) {
   for (;;) {
     // BVH descent (bvh.rs:58-76): test the node's own box over (tmin, best_t); left first, right deferred.
     while (NREF_KIND(node) == NK_BVH) {
-      const DBvhNode& n = S.bvh[NREF_INDEX(node)];
+      BvhRec n;
+      load_bvh<CACHE>(S, C, NREF_INDEX(node), n);
       cnt.bvh++;
       if (aabb_hit(n.box, r, tmin, best_t)) {
         st_push(st, n.right);
@@ -322,7 +410,9 @@ __device__ void traverse(const DScene& S, nref_t& node, TravRay& r, double tmin,
     if (kind == NK_SPHERE) {
       double t;
       cnt.prim++;
-      if (sphere_hit(S.spheres[idx], r, tmin, best_t, t)) { best_t = t; best = node; }
+      SphereRec sp;
+      load_sphere<CACHE>(S, C, idx, sp);
+      if (sphere_hit(sp, r, tmin, best_t, t)) { best_t = t; best = node; }
     } else if ((F & TF_QUADS) && kind == NK_QUAD) {
       double t, al, be;
       cnt.prim++;
@@ -550,6 +640,7 @@ __device__ inline V3 tex_value(const DScene& S, int tex, double u, double v, V3 
 __device__ inline double light_pdf_one(const DScene& S, const DLight& L, V3 origin, V3 dir) {
   TravRay r;
   r.o = origin; r.d = dir; r.time = 0.0;  // Ray::new -> time 0
+  r.dd = len2(dir);
   if (L.kind == LK_SPHERE) {
     const DSphere& s = S.spheres[L.index];
     double t;
@@ -726,9 +817,33 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_raygen(DScene S, PathPool P, Bat
 #ifndef CHIP_EXTEND_WAVES
 #define CHIP_EXTEND_WAVES 4
 #endif
-template <uint32_t F>
-__global__ void __launch_bounds__(CHIP_BLOCK, (F & TF_MEDIA) ? 1 : ((F & TF_XFORM) ? 2 : CHIP_EXTEND_WAVES)) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce) {
-  __shared__ uint32_t lds_stack[CHIP_STACK_LDS * CHIP_BLOCK];
+// What the traversal kernel keeps in LDS besides the per-lane stacks.
+struct CacheDesc {
+  uint32_t n_bvh, n_sph;     // leading BVH nodes / spheres copied into LDS (0 = no cache)
+  uint32_t stack_entries;    // per-lane stack entries kept in LDS
+};
+// Threads per block of the traversal kernel: with the LDS scene cache one block owns a whole CU's LDS.
+__host__ __device__ constexpr int extend_block(uint32_t F, bool CACHE) { return CACHE ? ((F & TF_MEDIA) ? 512 : 1024) : CHIP_BLOCK; }
+__host__ __device__ constexpr int extend_min_waves(uint32_t F, bool CACHE) {
+  return CACHE ? 1 : ((F & TF_MEDIA) ? 1 : ((F & TF_XFORM) ? 2 : CHIP_EXTEND_WAVES));
+}
+template <uint32_t F, bool CACHE>
+__global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CACHE)) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce, CacheDesc cd) {
+  // LDS layout: [4 x n_bvh uint4][4 x n_sph uint4][stack_entries x blockDim u32]
+  const NodeCache C{0u, 4u * cd.n_bvh, cd.n_bvh, cd.n_sph, cd.n_bvh, cd.n_sph};
+  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(g_lds) + 16u * (cd.n_bvh + cd.n_sph);
+  if (CACHE) {
+    for (uint32_t i = threadIdx.x; i < cd.n_bvh; i += blockDim.x) {
+      const uint4* p = reinterpret_cast<const uint4*>(S.bvh + i);
+      g_lds[i] = p[0]; g_lds[cd.n_bvh + i] = p[1]; g_lds[2 * cd.n_bvh + i] = p[2]; g_lds[3 * cd.n_bvh + i] = p[3];
+    }
+    const uint32_t so = 4u * cd.n_bvh;
+    for (uint32_t i = threadIdx.x; i < cd.n_sph; i += blockDim.x) {
+      const uint4* p = reinterpret_cast<const uint4*>(S.spheres + i);
+      g_lds[so + i] = p[0]; g_lds[so + cd.n_sph + i] = p[1]; g_lds[so + 2 * cd.n_sph + i] = p[2]; g_lds[so + 3 * cd.n_sph + i] = p[3];
+    }
+    __syncthreads();
+  }
   const uint32_t* q_in = P.q_live[bounce & 1];
   uint32_t* ctr = P.counters + (size_t)bounce * 8;
   const uint32_t n_live = ctr[0];
@@ -736,10 +851,12 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (F & TF_MEDIA) ? 1 : ((F & TF_XFOR
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = __lane_id();
   TravStack st;
-  st.lds = lds_stack + threadIdx.x;
+  st.lds = (lds_u32_t)lds_stack + threadIdx.x;
   st.ovf = P.ovf + (size_t)gtid * CHIP_STACK_OVF;
   st.overflow = 0;
   st.sp = 0;
+  st.lds_cap = (int)cd.stack_entries;
+  st.shift = 31 - __clz((int)blockDim.x);
   TravCounters cnt{0, 0};
   uint32_t nseg = 0;
   const size_t cap = P.cap;
@@ -754,7 +871,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (F & TF_MEDIA) ? 1 : ((F & TF_XFOR
   rng.init(B.seed_lo, B.seed_hi, 0, 0, bounce, 0);
   // chunk of the live queue a wave reserves at a time: large enough to keep the shared cursor cold,
   // small enough to leave every wave of the grid some work
-  const uint32_t n_waves = gridDim.x * (CHIP_BLOCK / 64);
+  const uint32_t n_waves = gridDim.x * (blockDim.x / 64);
   uint32_t chunk = (n_live / (n_waves * 4u)) & ~63u;
   chunk = chunk < 64u ? 64u : (chunk > 2048u ? 2048u : chunk);
   uint32_t w_next = 0, w_end = 0;  // wave-uniform
@@ -806,7 +923,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (F & TF_MEDIA) ? 1 : ((F & TF_XFOR
     }
     if (!__any(has) && exhausted) break;
     // 3. traverse until the rays are done or too few lanes are still busy
-    if (has) traverse<F, true>(S, node, r, 0.001, best_t, best, rng, st, 0, cnt, !(exhausted && w_next >= w_end));
+    if (has) traverse<F, true, CACHE>(S, C, node, r, 0.001, best_t, best, rng, st, 0, cnt, !(exhausted && w_next >= w_end));
   }
   if (st.overflow) atomicOr(&P.errflag[0], 1u);
   // per-wave reduction of the traversal counters
@@ -1065,9 +1182,12 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P,
   __shared__ uint32_t lds_stack[CHIP_STACK_LDS * CHIP_BLOCK];
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   TravStack st;
-  st.lds = lds_stack + threadIdx.x;
+  st.lds = (lds_u32_t)lds_stack + threadIdx.x;
   st.ovf = P.ovf + (size_t)gtid * CHIP_STACK_OVF;
   st.overflow = 0;
+  st.lds_cap = CHIP_STACK_LDS;
+  st.shift = 31 - __clz(CHIP_BLOCK);
+  const NodeCache none{0, 0, 0, 0, 0, 0};
   TravCounters cnt{0, 0};
   for (uint32_t i = gtid; i < n; i += gridDim.x * blockDim.x) {
     TravRay r;
@@ -1082,7 +1202,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P,
     nref_t best = NREF_NONE;
     st.sp = 0;
     nref_t node = S.root;
-    traverse<F, false>(S, node, r, 0.001, best_t, best, rng, st, 0, cnt);
+    traverse<F, false, false>(S, none, node, r, 0.001, best_t, best, rng, st, 0, cnt);
     DHitOut h;
     h.t = 0; h.u = 0; h.v = 0;
     for (int k = 0; k < 3; k++) { h.pt[k] = 0; h.normal[k] = 0; }

@@ -484,8 +484,50 @@ struct HostScene {
         fl.emit_light(handle[lights]);
       }
     }
+    reorder_bvh_breadth_first(F);
     if (F.bvh.size() >= (1u << 28) || F.spheres.size() >= (1u << 28) || F.quads.size() >= (1u << 28))
       throw std::runtime_error("scene too large for 28-bit node indices");
+  }
+
+  // Renumbers the BVH table breadth-first (world root first, then nested BVHs in order of discovery) so
+  // that the leading records are the top of the tree, which the traversal kernel keeps in LDS.
+  // Topology, boxes and child order are untouched; only the table indices change.
+  static void reorder_bvh_breadth_first(Flat& F) {
+    const size_t n = F.bvh.size();
+    if (n == 0) return;
+    std::vector<uint32_t> order;  // new index -> old index
+    order.reserve(n);
+    std::vector<uint32_t> newidx(n, 0xFFFFFFFFu);
+    auto bfs_from = [&](uint32_t root_old) {
+      if (newidx[root_old] != 0xFFFFFFFFu) return;
+      size_t head = order.size();
+      newidx[root_old] = (uint32_t)order.size();
+      order.push_back(root_old);
+      while (head < order.size()) {
+        const DBvhNode& b = F.bvh[order[head++]];
+        for (nref_t c : {b.left, b.right}) {
+          if (NREF_KIND(c) == NK_BVH && newidx[NREF_INDEX(c)] == 0xFFFFFFFFu) {
+            newidx[NREF_INDEX(c)] = (uint32_t)order.size();
+            order.push_back(NREF_INDEX(c));
+          }
+        }
+      }
+    };
+    if (NREF_KIND(F.root) == NK_BVH) bfs_from(NREF_INDEX(F.root));
+    for (uint32_t i = 0; i < n; i++) bfs_from(i);  // BVHs below groups / transforms / media, in table order
+    auto remap = [&](nref_t r) -> nref_t { return NREF_KIND(r) == NK_BVH ? NREF(NK_BVH, newidx[NREF_INDEX(r)]) : r; };
+    std::vector<DBvhNode> nb(n);
+    for (size_t i = 0; i < n; i++) {
+      nb[i] = F.bvh[order[i]];
+      nb[i].left = remap(nb[i].left);
+      nb[i].right = remap(nb[i].right);
+    }
+    F.bvh.swap(nb);
+    F.root = remap(F.root);
+    for (nref_t& c : F.gchild) c = remap(c);
+    for (DTranslate& t : F.translates) t.child = remap(t.child);
+    for (DRotate& t : F.rotates) t.child = remap(t.child);
+    for (DMedium& m : F.media) m.boundary = remap(m.boundary);
   }
 
   // Preorder dump in the order the reference's tree would be walked.
