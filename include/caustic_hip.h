@@ -85,7 +85,14 @@ typedef struct chip_stats {
   uint64_t batches;        /* path-pool batches in this call */
 } chip_stats;
 
-enum { CHIP_RENDER_TIME_KERNELS = 1 /* bracket traversal / shade launches with HIP events and report their durations */ };
+enum {
+  CHIP_RENDER_TIME_KERNELS = 1, /* bracket traversal / shade launches with HIP events and report their durations */
+  /* Shade kernels keep the reference's f64 operation order (divide, sqrt, sin, cos) for scatter directions and
+   * PDFs, so a render consumes the Philox stream exactly as the f64 CPU restatement does.  The default shade
+   * kernels use f32-seeded Newton reciprocals / f32 trigonometry there (same estimator, last-digit differences
+   * in sampled directions).  Traversal and hit records are f64 / reference order in both modes. */
+  CHIP_RENDER_EXACT_SHADING = 2
+};
 enum { CHIP_MAT_LAMBERTIAN = 0, CHIP_MAT_METAL = 1, CHIP_MAT_DIELECTRIC = 2, CHIP_MAT_DIFFUSE_LIGHT = 3, CHIP_MAT_ISOTROPIC = 4, CHIP_MAT_EMPTY = 5 };
 /* node kinds reported by chip_dump_tree */
 enum { CHIP_NODE_BVH = 0, CHIP_NODE_SPHERE = 1, CHIP_NODE_QUAD = 2, CHIP_NODE_GROUP = 3, CHIP_NODE_TRANSLATE = 4, CHIP_NODE_ROTATE = 5, CHIP_NODE_MEDIUM = 6, CHIP_NODE_BOX = 7 };

@@ -88,6 +88,7 @@ HIT_DTYPE = np.dtype(
 assert HIT_DTYPE.itemsize == 88
 
 RENDER_TIME_KERNELS = 1
+RENDER_EXACT_SHADING = 2  # shade kernels keep the reference's f64 operation order (see caustic_hip.h)
 
 NODE_KIND_NAMES = {0: "bvh", 1: "sphere", 2: "quad", 3: "group", 4: "translate", 5: "rotate", 6: "medium", 7: "box"}
 

@@ -73,9 +73,11 @@ struct chip_scene {
   // path pool
   bool pool_ready = false;
   PathPool pool;
-  DevBuf<double> p_ray, p_hit;
-  DevBuf<float> p_st, p_sample;
-  DevBuf<uint32_t> p_hinfo, p_draw, p_qlive0, p_qlive1, p_qmat, p_counters, p_err, p_ovf;
+  DevBuf<PathRay> p_ray;
+  DevBuf<PathHit> p_hit;
+  DevBuf<PathMap> p_st;
+  DevBuf<float4> p_sample;
+  DevBuf<uint32_t> p_qlive0, p_qlive1, p_qmat, p_counters, p_err, p_ovf;
   DevBuf<unsigned long long> p_stats;
   uint32_t counters_rows = 0;
   uint32_t* h_pinned = nullptr;
@@ -84,7 +86,7 @@ struct chip_scene {
     d_bvh.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release();
     d_translates.release(); d_rotates.release(); d_media.release(); d_xchain.release(); d_materials.release();
     d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
-    p_ray.release(); p_hit.release(); p_st.release(); p_sample.release(); p_hinfo.release(); p_draw.release();
+    p_ray.release(); p_hit.release(); p_st.release(); p_sample.release();
     p_qlive0.release(); p_qlive1.release(); p_qmat.release(); p_counters.release(); p_err.release(); p_ovf.release();
     p_stats.release();
     if (h_pinned) (void)hipHostFree(h_pinned);
@@ -119,12 +121,10 @@ static int ensure_pool(chip_scene* s) {
   if (s->pool_ready && s->counters_rows >= rows) return 0;
   size_t cap = pool_capacity_default();
   if (!s->pool_ready) {
-    HIP_TRY(s->p_ray.alloc(7 * cap));
+    HIP_TRY(s->p_ray.alloc(cap));
     HIP_TRY(s->p_hit.alloc(cap));
-    HIP_TRY(s->p_st.alloc(12 * cap));
-    HIP_TRY(s->p_sample.alloc(3 * cap));
-    HIP_TRY(s->p_hinfo.alloc(cap));
-    HIP_TRY(s->p_draw.alloc(cap));
+    HIP_TRY(s->p_st.alloc(cap));
+    HIP_TRY(s->p_sample.alloc(cap));
     HIP_TRY(s->p_qlive0.alloc(cap));
     HIP_TRY(s->p_qlive1.alloc(cap));
     HIP_TRY(s->p_qmat.alloc((size_t)MK_COUNT * cap));
@@ -137,7 +137,6 @@ static int ensure_pool(chip_scene* s) {
   s->counters_rows = rows;
   PathPool& P = s->pool;
   P.ray = s->p_ray.p; P.hit = s->p_hit.p; P.st = s->p_st.p; P.sample = s->p_sample.p;
-  P.hinfo = s->p_hinfo.p; P.draw = s->p_draw.p;
   P.q_live[0] = s->p_qlive0.p; P.q_live[1] = s->p_qlive1.p; P.q_mat = s->p_qmat.p;
   P.counters = s->p_counters.p; P.errflag = s->p_err.p; P.stats = s->p_stats.p; P.ovf = s->p_ovf.p;
   P.cap = (uint32_t)cap;
@@ -231,8 +230,9 @@ static void launch_extend(const chip_scene* s, uint32_t feat, uint32_t n_live_up
 }
 
 template <uint32_t K>
-static void launch_shade(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, uint32_t grid, hipStream_t st) {
-  hipLaunchKernelGGL(k_shade<K>, dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
+static void launch_shade(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, uint32_t grid, hipStream_t st, bool exact) {
+  if (exact) hipLaunchKernelGGL((k_shade<K, false>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
+  else hipLaunchKernelGGL((k_shade<K, true>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
 }
 
 // Adds the rectangle's radiance sums for the planned strata into d_sum (device, rw*rh*3 floats).
@@ -243,6 +243,7 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
   const DScene& S = s->dscene;
   const DCamera& cam = s->host.cam;
   const bool time_kernels = (o->flags & CHIP_RENDER_TIME_KERNELS) != 0;
+  const bool exact_shading = (o->flags & CHIP_RENDER_EXACT_SHADING) != 0;
   const uint32_t feat = scene_features(s->flat);
   uint32_t mat_mask = 0;
   for (const DMaterial& m : s->host.materials) mat_mask |= 1u << m.kind;  // scenes lacking a node family run a leaner traversal variant
@@ -291,12 +292,12 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
         n_trace_launches++;
         hipLaunchKernelGGL(k_bin, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, bounce, (uint32_t)((feat & TF_MEDIA) != 0));
         // only the material kinds the scene contains can have queue entries
-        if (mat_mask & (1u << MK_LAMBERTIAN)) launch_shade<MK_LAMBERTIAN>(S, P, B, bounce, grid, stream);
-        if (mat_mask & (1u << MK_METAL)) launch_shade<MK_METAL>(S, P, B, bounce, grid, stream);
-        if (mat_mask & (1u << MK_DIELECTRIC)) launch_shade<MK_DIELECTRIC>(S, P, B, bounce, grid, stream);
-        if (mat_mask & (1u << MK_DIFFUSE_LIGHT)) launch_shade<MK_DIFFUSE_LIGHT>(S, P, B, bounce, grid, stream);
-        if (mat_mask & (1u << MK_ISOTROPIC)) launch_shade<MK_ISOTROPIC>(S, P, B, bounce, grid, stream);
-        if (mat_mask & (1u << MK_EMPTY)) launch_shade<MK_EMPTY>(S, P, B, bounce, grid, stream);
+        if (mat_mask & (1u << MK_LAMBERTIAN)) launch_shade<MK_LAMBERTIAN>(S, P, B, bounce, grid, stream, exact_shading);
+        if (mat_mask & (1u << MK_METAL)) launch_shade<MK_METAL>(S, P, B, bounce, grid, stream, exact_shading);
+        if (mat_mask & (1u << MK_DIELECTRIC)) launch_shade<MK_DIELECTRIC>(S, P, B, bounce, grid, stream, exact_shading);
+        if (mat_mask & (1u << MK_DIFFUSE_LIGHT)) launch_shade<MK_DIFFUSE_LIGHT>(S, P, B, bounce, grid, stream, exact_shading);
+        if (mat_mask & (1u << MK_ISOTROPIC)) launch_shade<MK_ISOTROPIC>(S, P, B, bounce, grid, stream, exact_shading);
+        if (mat_mask & (1u << MK_EMPTY)) launch_shade<MK_EMPTY>(S, P, B, bounce, grid, stream, exact_shading);
         if (time_kernels) (void)hipEventRecord(new_event(), stream);
         // every few bounces learn how many paths are still alive (stops the loop early)
         if (bounce + 1 < cam.max_depth && (bounce % 4) == 3) {

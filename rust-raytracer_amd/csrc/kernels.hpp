@@ -22,14 +22,28 @@
 #define CHIP_PI 3.14159265358979323846
 #define CHIP_BIG 1e30f
 
-// ------------------------------------------------------------------ path pool (SoA, stride = capacity)
+// ------------------------------------------------------------------ path pool
+// After the first bounce the live paths are a sparse subset of the slots, so every kernel reads and
+// writes path state by gathered slot index.  The state is therefore stored as one small record per
+// path and per consumer (array of structures): a lane moves its record with a few 16-byte accesses
+// inside one or two cache lines instead of touching one line per scalar field.
+struct alignas(64) PathRay {  // what traversal reads and shading rewrites
+  double o[3], d[3], time;
+  double pad;
+};
+struct alignas(16) PathHit {  // what traversal writes: closest hit of the current segment
+  double t;
+  uint32_t node;  // node reference, NREF_NONE = miss
+  uint32_t draw;  // uniforms consumed during traversal (media free-flight samples)
+};
+struct alignas(16) PathMap {  // x -> clamp(a + b x, lo, hi), the composed radiance map of the path so far
+  float a[3], b[3], lo[3], hi[3];
+};
 struct PathPool {
-  double* ray;      // [7][cap]  origin xyz, direction xyz, time
-  double* hit;      // [cap]     t of the closest hit of the current segment
-  float* st;        // [12][cap] a rgb, b rgb, lo rgb, hi rgb of  x -> clamp(a + b x, lo, hi)
-  uint32_t* hinfo;  // [cap]     node reference of the closest hit (NREF_NONE = miss)
-  uint32_t* draw;   // [cap]     uniforms already consumed in the current bounce
-  float* sample;    // [3][cap]  finished sample radiance
+  PathRay* ray;     // [cap]
+  PathHit* hit;     // [cap]
+  PathMap* st;      // [cap]
+  float4* sample;   // [cap] finished sample radiance (rgb, w unused)
   uint32_t* q_live[2];  // [cap] live path slots, ping-pong per bounce
   uint32_t* q_mat;      // [MK_COUNT][cap] per-material-kind shade queues
   uint32_t* counters;   // [max_depth+2][8]: [b][0] live entering bounce b, [b][1..6] material queue sizes, [b][7] live-queue cursor
@@ -121,6 +135,8 @@ __device__ inline V3 mat_mul(const double* m, V3 v) {
 __device__ inline V3 mat_mulT(const double* m, V3 v) {
   return V3{m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z};
 }
+__device__ inline double fast_rsqrt(double x);
+template <bool FAST = false>
 __device__ inline V3 random_unit(Rng& r) {  // vector.rs:79-87
   V3 p = mk(1, 0, 0);
   for (int it = 0; it < CHIP_REJECT_CAP; it++) {
@@ -129,7 +145,7 @@ __device__ inline V3 random_unit(Rng& r) {  // vector.rs:79-87
     double z = r.interval(-1.0, 1.0);
     p = mk(x, y, z);
     double l2 = len2(p);
-    if (1e-160 < l2 && l2 <= 1.0) return p / sqrt(l2);
+    if (1e-160 < l2 && l2 <= 1.0) return FAST ? p * fast_rsqrt(fmax(l2, 1e-30)) : p / sqrt(l2);
   }
   return unit(p);
 }
@@ -493,6 +509,21 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
   }
 }
 
+// ------------------------------------------------------------------ fast shading arithmetic
+// The default shade kernels replace f64 divide / sqrt / sin / cos by an f32 seed plus one f64 Newton
+// step (relative error ~1e-14) or by f32 evaluation (sample directions only): scattered directions
+// then differ from the reference's arithmetic in the last digits, which only matters statistically.
+// CHIP_RENDER_EXACT_SHADING selects the variants that keep the reference's f64 operation order.
+__device__ inline double fast_rsqrt(double x) {
+  double y = (double)__frsqrt_rn((float)x);
+  return y * (1.5 - 0.5 * x * y * y);
+}
+__device__ inline double fast_rcp(double x) {
+  double y = (double)__frcp_rn((float)x);
+  return y * (2.0 - x * y);
+}
+__device__ inline V3 fast_unit(V3 a) { return a * fast_rsqrt(len2(a)); }
+
 struct HitOut {
   V3 pt, n;
   double u, v;
@@ -514,7 +545,7 @@ __device__ inline void sphere_uv(V3 p, double& u, double& v) {
 // constant_medium.rs:70-79), then carry it back out through the enclosing
 // Translate / Rotate nodes (translate.rs:34, rotate.rs:145-146).
 // want_uv = the material's texture reads (u, v); the sphere's acos / atan2 are skipped otherwise.
-template <uint32_t F>
+template <uint32_t F, bool FAST = false>
 __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo, V3 wd, double time, HitOut& h, bool want_uv = true) {
   uint32_t kind = NREF_KIND(leaf), idx = NREF_INDEX(leaf);
   nref_t x = NREF_NONE;
@@ -527,7 +558,7 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
   if (kind == NK_SPHERE) {
     const DSphere& s = S.spheres[idx];
     V3 center = ld3(s.c) + (time * ld3(s.dc));
-    V3 outward = (h.pt - center) / s.r;
+    V3 outward = FAST ? (h.pt - center) * fast_rcp(s.r) : (h.pt - center) / s.r;
     h.u = 0.0;
     h.v = 0.0;
     if (want_uv) sphere_uv(outward, h.u, h.v);
@@ -719,22 +750,17 @@ struct Affine {
   float a[3], b[3], lo[3], hi[3];
 };
 __device__ inline void affine_load(const PathPool& P, uint32_t slot, Affine& f) {
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    f.a[c] = P.st[(size_t)(0 + c) * P.cap + slot];
-    f.b[c] = P.st[(size_t)(3 + c) * P.cap + slot];
-    f.lo[c] = P.st[(size_t)(6 + c) * P.cap + slot];
-    f.hi[c] = P.st[(size_t)(9 + c) * P.cap + slot];
-  }
+  const float4* p = reinterpret_cast<const float4*>(P.st + slot);
+  float4 v0 = p[0], v1 = p[1], v2 = p[2];
+  f.a[0] = v0.x; f.a[1] = v0.y; f.a[2] = v0.z; f.b[0] = v0.w;
+  f.b[1] = v1.x; f.b[2] = v1.y; f.lo[0] = v1.z; f.lo[1] = v1.w;
+  f.lo[2] = v2.x; f.hi[0] = v2.y; f.hi[1] = v2.z; f.hi[2] = v2.w;
 }
 __device__ inline void affine_store(const PathPool& P, uint32_t slot, const Affine& f) {
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    P.st[(size_t)(0 + c) * P.cap + slot] = f.a[c];
-    P.st[(size_t)(3 + c) * P.cap + slot] = f.b[c];
-    P.st[(size_t)(6 + c) * P.cap + slot] = f.lo[c];
-    P.st[(size_t)(9 + c) * P.cap + slot] = f.hi[c];
-  }
+  float4* p = reinterpret_cast<float4*>(P.st + slot);
+  p[0] = make_float4(f.a[0], f.a[1], f.a[2], f.b[0]);
+  p[1] = make_float4(f.b[1], f.b[2], f.lo[0], f.lo[1]);
+  p[2] = make_float4(f.lo[2], f.hi[0], f.hi[1], f.hi[2]);
 }
 // One bounce of camera.rs:274-304 as the per-channel map x -> clamp(e + w x, klo, khi),
 // composed on the right of the path's x -> clamp(a + b x, lo, hi).
@@ -751,8 +777,22 @@ __device__ inline void affine_compose(Affine& f, const float e[3], const float w
   }
 }
 __device__ inline void finish_path(const PathPool& P, uint32_t slot, const Affine& f, const float x[3]) {
-#pragma unroll
-  for (int c = 0; c < 3; c++) P.sample[(size_t)c * P.cap + slot] = fclampf(f.a[c] + f.b[c] * x[c], f.lo[c], f.hi[c]);
+  P.sample[slot] = make_float4(fclampf(f.a[0] + f.b[0] * x[0], f.lo[0], f.hi[0]), fclampf(f.a[1] + f.b[1] * x[1], f.lo[1], f.hi[1]),
+                               fclampf(f.a[2] + f.b[2] * x[2], f.lo[2], f.hi[2]), 0.f);
+}
+// 16-byte accesses of a path's ray record
+__device__ inline void ray_load(const PathPool& P, uint32_t slot, V3& o, V3& d, double& time) {
+  const double2* p = reinterpret_cast<const double2*>(P.ray + slot);
+  double2 a = p[0], b = p[1], c = p[2], e = p[3];
+  o = mk(a.x, a.y, b.x);
+  d = mk(b.y, c.x, c.y);
+  time = e.x;
+}
+__device__ inline void ray_store_od(const PathPool& P, uint32_t slot, V3 o, V3 d) {
+  double2* p = reinterpret_cast<double2*>(P.ray + slot);
+  p[0] = make_double2(o.x, o.y);
+  p[1] = make_double2(o.z, d.x);
+  p[2] = make_double2(d.y, d.z);
 }
 
 __device__ inline void slot_to_path(const BatchDesc& B, const DCamera& cam, uint32_t slot, uint32_t& x, uint32_t& y, uint32_t& pixel,
@@ -796,15 +836,13 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_raygen(DScene S, PathPool P, Bat
     V3 o, d;
     double time;
     camera_ray(S.cam, rng, x, y, stratum % S.cam.sqrt_spp, stratum / S.cam.sqrt_spp, o, d, time);
-    size_t cap = P.cap;
-    P.ray[0 * cap + slot] = o.x; P.ray[1 * cap + slot] = o.y; P.ray[2 * cap + slot] = o.z;
-    P.ray[3 * cap + slot] = d.x; P.ray[4 * cap + slot] = d.y; P.ray[5 * cap + slot] = d.z;
-    P.ray[6 * cap + slot] = time;
+    ray_store_od(P, slot, o, d);
+    reinterpret_cast<double2*>(P.ray + slot)[3] = make_double2(time, 0.0);
     Affine f;
 #pragma unroll
     for (int c = 0; c < 3; c++) { f.a[c] = 0.f; f.b[c] = 1.f; f.lo[c] = -CHIP_BIG; f.hi[c] = CHIP_BIG; }
     affine_store(P, slot, f);
-    P.sample[0 * cap + slot] = 0.f; P.sample[1 * cap + slot] = 0.f; P.sample[2 * cap + slot] = 0.f;
+    P.sample[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     P.q_live[0][slot] = slot;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[0] = B.n_paths;
@@ -880,9 +918,11 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
     // 1. lanes whose traversal finished store (t, node); the HitRecord is rebuilt where it is consumed
     if (has && node == NREF_NONE) {
       nseg++;
-      P.hit[slot] = best_t;
-      P.hinfo[slot] = best;
-      if (F & TF_MEDIA) P.draw[slot] = rng.draw;
+      PathHit ph;
+      ph.t = best_t;
+      ph.node = best;
+      ph.draw = (F & TF_MEDIA) ? rng.draw : 0u;
+      *reinterpret_cast<uint4*>(P.hit + slot) = *reinterpret_cast<const uint4*>(&ph);
       has = false;
     }
     // 2. idle lanes take the next entries of the wave's current chunk of the live queue; a new chunk is
@@ -902,9 +942,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
         const uint32_t avail = w_end - w_next;
         if (!has && rank < avail) {
           slot = q_in[w_next + rank];
-          r.wo = mk(P.ray[0 * cap + slot], P.ray[1 * cap + slot], P.ray[2 * cap + slot]);
-          r.wd = mk(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
-          r.time = P.ray[6 * cap + slot];
+          ray_load(P, slot, r.wo, r.wd, r.time);
           r.o = r.wo; r.d = r.wd;
           ray_set_inv(r);
           if (F & TF_MEDIA) {
@@ -971,7 +1009,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_bin(DScene S, PathPool P, uint32
     const uint32_t tile_n = min(tile, n_live - tile0);
     for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
       const uint32_t slot = q_in[tile0 + k];
-      const nref_t best = P.hinfo[slot];
+      const nref_t best = P.hit[slot].node;
       uint32_t kind = MK_COUNT;
       if (best == NREF_NONE) {
         Affine f;
@@ -980,7 +1018,6 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_bin(DScene S, PathPool P, uint32
         finish_path(P, slot, f, bg);
       } else {
         kind = S.materials[node_material(S, best)].kind;
-        if (!has_media) P.draw[slot] = 0u;
         s_rank[k] = (uint16_t)atomicAdd(&s_cnt[kind], 1u);
       }
       s_slot[k] = slot;
@@ -999,7 +1036,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_bin(DScene S, PathPool P, uint32
 
 // Material-binned shade: Material::emitted / scatter / scattering_pdf plus the PDF branch of
 // camera.rs:278-305 for one material kind.
-template <uint32_t KIND>
+template <uint32_t KIND, bool FAST>
 __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, BatchDesc B, uint32_t bounce) {
   uint32_t* ctr = P.counters + (size_t)bounce * 8;
   uint32_t* ctr_next = P.counters + (size_t)(bounce + 1) * 8;
@@ -1025,12 +1062,15 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, Batc
       Affine f;
       affine_load(P, slot, f);
       // HitRecord of the segment's closest hit (object/mod.rs:31-51), rebuilt from (ray, t, node)
-      const nref_t leaf = P.hinfo[slot];
+      PathHit ph;
+      *reinterpret_cast<uint4*>(&ph) = *reinterpret_cast<const uint4*>(P.hit + slot);
+      const nref_t leaf = ph.node;
       const DMaterial& M = S.materials[node_material(S, leaf)];
-      V3 ro = mk(P.ray[0 * cap + slot], P.ray[1 * cap + slot], P.ray[2 * cap + slot]);
-      V3 rd = mk(P.ray[3 * cap + slot], P.ray[4 * cap + slot], P.ray[5 * cap + slot]);
+      V3 ro, rd;
+      double rtime;
+      ray_load(P, slot, ro, rd, rtime);
       HitOut hrec;
-      reconstruct<TF_QUADS | TF_XFORM | TF_MEDIA>(S, leaf, P.hit[slot], ro, rd, P.ray[6 * cap + slot], hrec, (M.flags & MF_NEEDS_UV) != 0);
+      reconstruct<TF_QUADS | TF_XFORM | TF_MEDIA, FAST>(S, leaf, ph.t, ro, rd, rtime, hrec, (M.flags & MF_NEEDS_UV) != 0);
       const bool front = hrec.front;
       const V3 pt = hrec.pt;
       if (KIND == MK_DIFFUSE_LIGHT) {
@@ -1049,18 +1089,18 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, Batc
         uint32_t x_, y_, pixel, stratum;
         slot_to_path(B, S.cam, slot, x_, y_, pixel, stratum);
         Rng rng;
-        rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, P.draw[slot]);
+        rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, ph.draw);
         V3 ndir;
         bool terminal = false;
         float e[3] = {0.f, 0.f, 0.f}, w[3];
         float klo = -CHIP_BIG, khi = CHIP_BIG;
         if (KIND == MK_METAL) {  // metal.rs:20-28
           V3 reflected = reflect(rd, nrm);
-          ndir = unit(reflected) + (M.p[3] * random_unit(rng));
+          ndir = (FAST ? fast_unit(reflected) : unit(reflected)) + (M.p[3] * random_unit<FAST>(rng));
           w[0] = (float)M.p[0]; w[1] = (float)M.p[1]; w[2] = (float)M.p[2];
         } else if (KIND == MK_DIELECTRIC) {  // dielectric.rs:30-52
           double ri = front ? 1.0 / M.p[0] : M.p[0];
-          V3 ud = unit(rd);
+          V3 ud = FAST ? fast_unit(rd) : unit(rd);
           double cos_theta = fmin(dot(-ud, nrm), 1.0);
           double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
           bool cannot_refract = ri * sin_theta > 1.0;
@@ -1081,10 +1121,45 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, Batc
           V3 atten = tex_value(S, M.tex, hrec.u, hrec.v, pt);
           bool use_light = false;
           if (S.has_lights) use_light = rng.next() < 0.5;  // mixture.rs:26-32
+          if (FAST) {
+            // same estimator with the fast arithmetic above; the hit normal is already unit length
+            V3 ow = nrm, ou = nrm, ov = nrm;
+            double local_z = 0.0;
+            if (KIND == MK_LAMBERTIAN) {
+              V3 a = fabs(ow.x) > 0.9 ? mk(0.0, 1.0, 0.0) : mk(1.0, 0.0, 0.0);
+              ov = fast_unit(cross(ow, a));
+              ou = cross(ow, ov);
+            }
+            if (use_light) {
+              ndir = lights_random(S, pt, rng);
+            } else if (KIND == MK_LAMBERTIAN) {
+              float r1 = (float)rng.next(), r2 = (float)rng.next();
+              float sn, cs;
+              sincospif(2.0f * r1, &sn, &cs);
+              float sq = sqrtf(r2);
+              local_z = (double)sqrtf(1.0f - r2);
+              ndir = ((double)(cs * sq) * ou) + ((double)(sn * sq) * ov) + (local_z * ow);
+            } else {
+              ndir = random_unit<true>(rng);
+            }
+            double cos_n = 0.0;  // cosine between the scattered direction and the normal
+            if (KIND == MK_LAMBERTIAN) cos_n = (use_light || S.has_lights) ? dot(fast_unit(ndir), ow) : local_z;
+            double mat_pdf = KIND == MK_LAMBERTIAN ? fmax(cos_n * (1.0 / CHIP_PI), 0.0) : 1.0 / (4.0 * CHIP_PI);
+            double pv = mat_pdf;
+            if (S.has_lights) pv = 0.5 * lights_pdf(S, pt, ndir) + 0.5 * mat_pdf;
+            if (pv < 0.05) {
+              terminal = true;
+            } else {
+              double sp = KIND == MK_LAMBERTIAN ? (cos_n < 0.0 ? 0.0 : cos_n * (1.0 / CHIP_PI)) : 1.0 / (4.0 / CHIP_PI);
+              double k = (KIND == MK_LAMBERTIAN && !S.has_lights) ? 1.0 : sp * fast_rcp(pv);  // cosine sampling alone: sp == pv
+              w[0] = (float)(atten.x * k); w[1] = (float)(atten.y * k); w[2] = (float)(atten.z * k);
+              klo = 0.f; khi = 10.f;
+            }
+          } else {
           Onb uvw(nrm);                                    // cosine.rs:10-14 (unused for Isotropic)
           if (use_light) ndir = lights_random(S, pt, rng);
           else if (KIND == MK_LAMBERTIAN) ndir = uvw.local(random_cosine_direction(rng));  // cosine.rs:24-27
-          else ndir = random_unit(rng);                                                   // probability_density_function/sphere.rs:24-26
+          else ndir = random_unit<false>(rng);                                            // probability_density_function/sphere.rs:24-26
           double mat_pdf;
           if (KIND == MK_LAMBERTIAN) mat_pdf = fmax(dot(unit(ndir), uvw.w) / CHIP_PI, 0.0);  // cosine.rs:18-22
           else mat_pdf = 1.0 / (4.0 * CHIP_PI);                                              // sphere.rs:20-22
@@ -1107,6 +1182,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, Batc
             w[0] = (float)(atten.x * sp / pv); w[1] = (float)(atten.y * sp / pv); w[2] = (float)(atten.z * sp / pv);
             klo = 0.f; khi = 10.f;  // camera.rs:304
           }
+          }
         }
         if (terminal) {
           float x[3] = {0.f, 0.f, 0.f};
@@ -1118,8 +1194,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, Batc
             finish_path(P, slot, f, x);
           } else {
             affine_store(P, slot, f);
-            P.ray[0 * cap + slot] = pt.x; P.ray[1 * cap + slot] = pt.y; P.ray[2 * cap + slot] = pt.z;
-            P.ray[3 * cap + slot] = ndir.x; P.ray[4 * cap + slot] = ndir.y; P.ray[5 * cap + slot] = ndir.z;
+            ray_store_od(P, slot, pt, ndir);  // the time of the path's rays never changes (camera.rs:287)
             cont = true;
           }
         }
@@ -1145,10 +1220,10 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_accumulate(PathPool P, BatchDesc
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < B.npix; p += gridDim.x * blockDim.x) {
     float r = 0.f, g = 0.f, b = 0.f;
     for (uint32_t sb = 0; sb < B.n_strata; sb++) {
-      size_t slot = (size_t)sb * B.npix + p;
-      r += P.sample[0 * (size_t)P.cap + slot];
-      g += P.sample[1 * (size_t)P.cap + slot];
-      b += P.sample[2 * (size_t)P.cap + slot];
+      const float4 v = P.sample[(size_t)sb * B.npix + p];
+      r += v.x;
+      g += v.y;
+      b += v.z;
     }
     sum_rgb[(size_t)p * 3 + 0] += r;
     sum_rgb[(size_t)p * 3 + 1] += g;

@@ -16,7 +16,7 @@ def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
 
 
-def _check(sc, g, name, exact_image, sum_dtype):
+def _check(sc, g, name, exact_image, sum_dtype, flags=0):
     hits = sc.trace_rays(g[name + "/o"], g[name + "/d"], g[name + "/time"], seed=9)
     assert np.array_equal(hits["hit"], g[name + "/hit"].astype(np.int32))
     m = hits["hit"] == 1
@@ -25,7 +25,7 @@ def _check(sc, g, name, exact_image, sum_dtype):
     assert rel.max() <= 1e-5
     assert np.abs(hits["normal"][m] - g[name + "/normal"][m]).max() <= 1e-5
     assert np.abs(np.stack([hits["u"], hits["v"]], axis=1)[m] - g[name + "/uv"][m]).max() <= 1e-5
-    img, _, st = sc.render_frame(seed=21, sum_dtype=sum_dtype)
+    img, _, st = sc.render_frame(seed=21, sum_dtype=sum_dtype, flags=flags)
     want = g[name + "/image_sum"]
     if exact_image:
         assert np.array_equal(img, want)
@@ -55,4 +55,4 @@ def test_oracle_reproduces_golden(pkg, oracle, golden, name):
 @pytest.mark.parametrize("name", SCENES)
 def test_gpu_reproduces_golden(pkg, gpu, golden, name):
     sc = pkg.scenes.build(gpu, name, **KW)
-    _check(sc, golden, name, exact_image=False, sum_dtype=np.float32)
+    _check(sc, golden, name, exact_image=False, sum_dtype=np.float32, flags=pkg.bindings.RENDER_EXACT_SHADING)

@@ -64,9 +64,10 @@ def test_fixed_ray_set_hits(pkg, gpu, oracle, name):
 
 @pytest.mark.parametrize("name", ALL_SCENES)
 def test_same_seed_render_matches_oracle(pkg, gpu, oracle, name):
+    """Exact-shading mode consumes the Philox stream exactly as the oracle does: identical paths."""
     kw = dict(width=80, spp=16, depth=12)
     sg, so = build_pair(pkg, gpu, oracle, name, **kw)
-    img_g, rgb8_g, st_g = sg.render_frame(seed=21, want_rgb8=True)
+    img_g, rgb8_g, st_g = sg.render_frame(seed=21, want_rgb8=True, flags=pkg.bindings.RENDER_EXACT_SHADING)
     img_o, rgb8_o, st_o = so.render_frame(seed=21, want_rgb8=True, sum_dtype=np.float64)
     assert st_g["paths"] == st_o["paths"]
     diff = np.abs(img_g.astype(np.float64) - img_o)
@@ -76,6 +77,23 @@ def test_same_seed_render_matches_oracle(pkg, gpu, oracle, name):
     assert bad.mean() < 2e-3
     assert abs(st_g["segments"] - st_o["segments"]) <= 2e-4 * st_o["segments"] + 4
     assert (np.abs(rgb8_g.astype(int) - rgb8_o.astype(int)) > 1).mean() < 2e-3
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_same_seed_default_shading_close_to_oracle(pkg, gpu, oracle, name):
+    """Default (fast-arithmetic) shading: same uniforms, sample directions equal to ~1e-7, so nearly every
+    path is still the oracle's path; the few that an ulp sends elsewhere bound the differing fraction."""
+    kw = dict(width=80, spp=16, depth=12)
+    sg, so = build_pair(pkg, gpu, oracle, name, **kw)
+    img_g, _, st_g = sg.render_frame(seed=21)
+    img_o, _, st_o = so.render_frame(seed=21, sum_dtype=np.float64)
+    diff = np.abs(img_g.astype(np.float64) - img_o)
+    bad = diff > 2e-3 * (1.0 + np.abs(img_o))
+    print(name, "segments gpu/oracle", st_g["segments"], st_o["segments"], "bad fraction", bad.mean(), "max diff", diff.max())
+    assert bad.mean() < 1e-2
+    assert abs(st_g["segments"] - st_o["segments"]) <= 2e-3 * st_o["segments"] + 8
+    # means agree far inside the Monte Carlo noise
+    assert abs(img_g.mean() - img_o.mean()) <= 2e-3 * abs(img_o.mean()) + 1e-6
 
 
 def test_image_psnr_and_variance_vs_independent_oracle(pkg, gpu, oracle):
