@@ -27,7 +27,7 @@ pkg = importlib.import_module("rust-raytracer_amd")
 # Device table sizes that define the algorithmic bytes of one ray segment of the traversal kernel.
 BYTES_BVH_NODE = 64    # DBvhNode: own box (6 f64) + two child refs, one 64-B record per visit
 BYTES_SPHERE = 80      # DSphere: centre, motion, radius (7 f64) + material / transform / id words
-BYTES_SEGMENT_STATE = 56 + 4 + 76 + 4 + 4 + 4  # ray read, queue read, hit record write, hinfo, draw, queue write
+BYTES_SEGMENT_STATE = 64 + 4 + 16  # PathRay record read, live-queue entry read, PathHit record write
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
@@ -153,7 +153,7 @@ def main():
                 "render_seed": args.seed,
             },
             "roofline": {
-                "kernel": "k_extend<false> (BVH traversal + sphere tests, f64)",
+                "kernel": "k_extend<0, true> (BVH traversal + sphere tests, f64, LDS scene cache)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
