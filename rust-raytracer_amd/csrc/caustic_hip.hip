@@ -56,6 +56,7 @@ struct chip_scene {
   int n_cus = 256;
   Flat flat;
   DevBuf<DBvhNode> d_bvh;
+  DevBuf<DTNode> d_tnodes;
   DevBuf<DSphere> d_spheres;
   DevBuf<DQuad> d_quads;
   DevBuf<DGroup> d_groups;
@@ -83,7 +84,7 @@ struct chip_scene {
   uint32_t* h_pinned = nullptr;
 
   void release_device() {
-    d_bvh.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release();
+    d_bvh.release(); d_tnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release();
     d_translates.release(); d_rotates.release(); d_media.release(); d_xchain.release(); d_materials.release();
     d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
     p_ray.release(); p_hit.release(); p_st.release(); p_sample.release();
@@ -107,20 +108,39 @@ static uint32_t scene_features(const Flat& F) {
 static const uint32_t kMaxGridBlocksDef = 2048;
 static const uint32_t kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 
-static size_t pool_capacity_default() {
+// Largest path pool a render may use.  Every bounce of a batch is one round of kernel launches, and the
+// late bounces of a batch carry few paths, so batches are made as large as the frame allows: the
+// default of 2^28 path slots (176 B each, 47 GB) leaves that tail at a few per cent of a 1080p frame.
+static size_t pool_capacity_max() {
   const char* e = getenv("CHIP_POOL_PATHS");
   if (e && *e) {
     long long v = atoll(e);
     if (v >= 4096) return (size_t)v;
   }
-  return (size_t)1 << 24;
+  return (size_t)1 << 28;
 }
+static const size_t kBytesPerPathSlot = sizeof(PathRay) + sizeof(PathHit) + sizeof(PathMap) + sizeof(float4) + sizeof(uint32_t) * (2 + MK_COUNT);
 
-static int ensure_pool(chip_scene* s) {
+// Makes the pool hold min(want_paths, the maximum above, what fits in free device memory) path slots.
+static int ensure_pool(chip_scene* s, size_t want_paths) {
   uint32_t rows = s->host.cam.max_depth + 2;
-  if (s->pool_ready && s->counters_rows >= rows) return 0;
-  size_t cap = pool_capacity_default();
+  size_t cap = std::min(std::max<size_t>(want_paths, 4096), pool_capacity_max());
+  if (!(s->pool_ready && s->pool.cap >= cap)) {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (s->pool_ready) free_b += (size_t)s->pool.cap * kBytesPerPathSlot;
+    cap = std::min(cap, std::max<size_t>(4096, (size_t)(0.8 * (double)free_b) / kBytesPerPathSlot));
+  }
+  if (s->pool_ready && s->pool.cap >= cap && s->counters_rows >= rows) return 0;
   if (!s->pool_ready) {
+    HIP_TRY(s->p_err.alloc(4));
+    HIP_TRY(s->p_stats.alloc(4));
+    HIP_TRY(s->p_ovf.alloc((size_t)kMaxGridBlocks * CHIP_BLOCK * CHIP_STACK_OVF * 2));
+    HIP_TRY(hipHostMalloc((void**)&s->h_pinned, 64 * sizeof(uint32_t), hipHostMallocDefault));
+  }
+  if (!s->pool_ready || s->pool.cap < cap) {
+    s->p_ray.release(); s->p_hit.release(); s->p_st.release(); s->p_sample.release();
+    s->p_qlive0.release(); s->p_qlive1.release(); s->p_qmat.release();
     HIP_TRY(s->p_ray.alloc(cap));
     HIP_TRY(s->p_hit.alloc(cap));
     HIP_TRY(s->p_st.alloc(cap));
@@ -128,18 +148,16 @@ static int ensure_pool(chip_scene* s) {
     HIP_TRY(s->p_qlive0.alloc(cap));
     HIP_TRY(s->p_qlive1.alloc(cap));
     HIP_TRY(s->p_qmat.alloc((size_t)MK_COUNT * cap));
-    HIP_TRY(s->p_err.alloc(4));
-    HIP_TRY(s->p_stats.alloc(4));
-    HIP_TRY(s->p_ovf.alloc((size_t)kMaxGridBlocks * CHIP_BLOCK * CHIP_STACK_OVF));
-    HIP_TRY(hipHostMalloc((void**)&s->h_pinned, 64 * sizeof(uint32_t), hipHostMallocDefault));
+    s->pool.cap = (uint32_t)cap;
   }
-  HIP_TRY(s->p_counters.alloc((size_t)rows * 8));
-  s->counters_rows = rows;
+  if (s->counters_rows < rows) {
+    HIP_TRY(s->p_counters.alloc((size_t)rows * 8));
+    s->counters_rows = rows;
+  }
   PathPool& P = s->pool;
   P.ray = s->p_ray.p; P.hit = s->p_hit.p; P.st = s->p_st.p; P.sample = s->p_sample.p;
   P.q_live[0] = s->p_qlive0.p; P.q_live[1] = s->p_qlive1.p; P.q_mat = s->p_qmat.p;
   P.counters = s->p_counters.p; P.errflag = s->p_err.p; P.stats = s->p_stats.p; P.ovf = s->p_ovf.p;
-  P.cap = (uint32_t)cap;
   s->pool_ready = true;
   return 0;
 }
@@ -189,8 +207,9 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat) {
   p.cache = !s->flat.bvh.empty() && !(e && *e == '1');
   if (p.cache) {
     p.block = (feat & TF_MEDIA) ? 512 : 1024;
-    p.cd.stack_entries = 12;
-    uint32_t stack_bytes = p.cd.stack_entries * 4 * p.block;
+    const bool ordered = !(feat & TF_MEDIA);  // ordered variants keep an entry distance beside every stack value
+    p.cd.stack_entries = ordered ? 10 : 12;
+    uint32_t stack_bytes = p.cd.stack_entries * (ordered ? 8 : 4) * p.block;
     uint32_t budget = (kLdsBytes - stack_bytes) / 64;
     p.cd.n_bvh = (uint32_t)std::min<size_t>(s->flat.bvh.size(), budget);
     p.cd.n_sph = (uint32_t)std::min<size_t>(s->flat.spheres.size(), budget - p.cd.n_bvh);
@@ -199,7 +218,7 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat) {
     p.block = CHIP_BLOCK;
     p.cd.stack_entries = CHIP_STACK_LDS;
     p.cd.n_bvh = p.cd.n_sph = 0;
-    p.lds_bytes = CHIP_STACK_LDS * 4 * CHIP_BLOCK;
+    p.lds_bytes = CHIP_STACK_LDS * 8 * CHIP_BLOCK;
   }
   return p;
 }
@@ -238,7 +257,7 @@ static void launch_shade(const DScene& S, const PathPool& P, const BatchDesc& B,
 // Adds the rectangle's radiance sums for the planned strata into d_sum (device, rw*rh*3 floats).
 static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPlan& pl, float* d_sum, hipStream_t stream, chip_stats* stats) {
   HIP_TRY(hipSetDevice(s->device));
-  if (ensure_pool(s)) return -1;
+  if (ensure_pool(s, (size_t)pl.rw * pl.rh * std::max<uint32_t>(pl.s_count, 1))) return -1;
   const PathPool& P = s->pool;
   const DScene& S = s->dscene;
   const DCamera& cam = s->host.cam;
@@ -610,6 +629,7 @@ int chip_commit(chip_scene* s) {
     s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   HIP_TRY(s->d_bvh.upload(F.bvh));
+  HIP_TRY(s->d_tnodes.upload(F.tnodes));
   HIP_TRY(s->d_spheres.upload(F.spheres));
   HIP_TRY(s->d_quads.upload(F.quads));
   HIP_TRY(s->d_groups.upload(F.groups));
@@ -638,7 +658,7 @@ int chip_commit(chip_scene* s) {
   if (F.has_lights && F.lights.empty() && !F.lights_is_group) return fail("internal: empty light list");
   HIP_TRY(s->d_lights.upload(F.lights));
   DScene& D = s->dscene;
-  D.bvh = s->d_bvh.p; D.spheres = s->d_spheres.p; D.quads = s->d_quads.p; D.groups = s->d_groups.p; D.gchild = s->d_gchild.p;
+  D.bvh = s->d_bvh.p; D.tnodes = s->d_tnodes.p; D.spheres = s->d_spheres.p; D.quads = s->d_quads.p; D.groups = s->d_groups.p; D.gchild = s->d_gchild.p;
   D.translates = s->d_translates.p; D.rotates = s->d_rotates.p; D.media = s->d_media.p; D.xchain = s->d_xchain.p;
   D.materials = s->d_materials.p; D.textures = s->d_textures.p; D.perlins = s->d_perlins.p; D.texels = s->d_texels.p;
   D.lights = s->d_lights.p;
@@ -737,7 +757,7 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
   if (n > 0xFFFFFFFFull) return fail("too many rays");
   static_assert(sizeof(chip_hit) == sizeof(DHitOut), "hit layout");
   HIP_TRY(hipSetDevice(s->device));
-  if (ensure_pool(s)) return -1;
+  if (ensure_pool(s, 0)) return -1;
   DevBuf<double> d_o, d_d, d_t;
   DevBuf<DHitOut> d_out;
   int rc = 0;

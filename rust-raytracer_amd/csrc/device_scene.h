@@ -32,6 +32,17 @@ struct alignas(64) DBvhNode {
   uint32_t pad[2];
 };
 
+// Traversal image of one BVH node: the boxes of its two children, rounded outward to f32, and the child
+// references (same index as the node's DBvhNode).  Used only for culling: a child is skipped when its
+// box cannot contain a hit closer than the current one, so these boxes only have to be conservative.
+// A BVH built from one node stores that node twice (bvh.rs:27-28); the duplicate gets an empty box.
+struct alignas(64) DTNode {
+  float lbox[6];  // left child: xmin,xmax,ymin,ymax,zmin,zmax
+  float rbox[6];  // right child
+  nref_t left, right;
+  uint32_t pad[2];
+};
+
 struct alignas(16) DSphere {
   double c[3];   // center at time 0
   double dc[3];  // center motion per unit time
@@ -39,7 +50,7 @@ struct alignas(16) DSphere {
   uint32_t mat;
   nref_t xform;  // innermost Translate/Rotate ancestor, or NREF_NONE
   int32_t leaf_id;
-  uint32_t pad;
+  uint32_t seq;  // position of this primitive in the reference's depth-first visiting order
 };
 
 struct alignas(16) DQuad {
@@ -48,7 +59,7 @@ struct alignas(16) DQuad {
   uint32_t mat;
   nref_t xform;
   int32_t leaf_id;
-  uint32_t pad;
+  uint32_t seq;  // as DSphere::seq
 };
 
 struct DGroup {
@@ -115,6 +126,7 @@ struct DCamera {  // Camera, camera.rs:202-231
 
 struct DScene {
   const DBvhNode* bvh;
+  const DTNode* tnodes;
   const DSphere* spheres;
   const DQuad* quads;
   const DGroup* groups;

@@ -49,7 +49,7 @@ struct PathPool {
   uint32_t* counters;   // [max_depth+2][8]: [b][0] live entering bounce b, [b][1..6] material queue sizes, [b][7] live-queue cursor
   uint32_t* errflag;    // [4]: [0] traversal stack overflow
   unsigned long long* stats;  // [4]: segments, bvh visits, prim tests, spare
-  uint32_t* ovf;        // [threads][CHIP_STACK_OVF] traversal stack spill
+  uint32_t* ovf;        // [threads][2 * CHIP_STACK_OVF] traversal stack spill (value, distance pairs)
   uint32_t cap;
 };
 
@@ -175,6 +175,11 @@ struct TravRay {
   V3 o, d, inv;     // ray in the current node's space and 1/d (aabb.rs:202)
   double dd;        // direction.length_squared() of d (sphere.rs:102)
   double time;
+  // f32 culling form of the ray (ordered traversal): the slab distance of a box plane b is
+  // fma(b, m, c) with m ~ 1/d and c ~ -o/d, biased so that entry distances come out too small and exit
+  // distances too large; capf is the current closest hit rounded up.
+  float m_lo[3], m_hi[3], c_lo[3], c_hi[3];
+  float capf;
 };
 // The traversal kernel's dynamic LDS: [scene cache records][per-lane stacks].  Declared at file scope so
 // that device functions index it directly and the compiler emits ds_read / ds_write (a pointer to it
@@ -214,16 +219,43 @@ struct TravCounters {
   uint32_t bvh, prim;
 };
 
-__device__ inline void st_push(TravStack& s, uint32_t v) {
-  if (s.sp < s.lds_cap) s.lds[s.sp << s.shift] = v;
-  else if (s.sp < s.lds_cap + CHIP_STACK_OVF) s.ovf[s.sp - s.lds_cap] = v;
-  else { s.overflow = 1; return; }
+// Entries are (value, entry distance) pairs in the ordered traversal (WITH_T): a deferred child is
+// dropped when it is popped if the closest hit found meanwhile is nearer than the child's box.
+// Markers and raw words are pushed with distance 0 and always survive.
+template <bool WITH_T>
+__device__ inline void st_push(TravStack& s, uint32_t v, float t = 0.0f) {
+  if (s.sp < s.lds_cap) {
+    s.lds[s.sp << s.shift] = v;
+    if (WITH_T) s.lds[(s.sp + s.lds_cap) << s.shift] = __float_as_uint(t);
+  } else if (s.sp < s.lds_cap + CHIP_STACK_OVF) {
+    if (WITH_T) { s.ovf[2 * (s.sp - s.lds_cap)] = v; s.ovf[2 * (s.sp - s.lds_cap) + 1] = __float_as_uint(t); }
+    else s.ovf[s.sp - s.lds_cap] = v;
+  } else { s.overflow = 1; return; }
   s.sp++;
 }
-__device__ inline uint32_t st_pop(TravStack& s, int base) {
+__device__ inline uint32_t st_pop_raw(TravStack& s, int base, bool with_t) {
   if (s.sp <= base) return NREF_NONE;
   s.sp--;
-  return s.sp < s.lds_cap ? s.lds[s.sp << s.shift] : s.ovf[s.sp - s.lds_cap];
+  return s.sp < s.lds_cap ? s.lds[s.sp << s.shift] : s.ovf[with_t ? 2 * (s.sp - s.lds_cap) : s.sp - s.lds_cap];
+}
+template <bool WITH_T>
+__device__ inline uint32_t st_pop(TravStack& s, int base, float capf = 0.0f) {
+  for (;;) {
+    if (s.sp <= base) return NREF_NONE;
+    s.sp--;
+    uint32_t v;
+    float t = 0.0f;
+    if (s.sp < s.lds_cap) {
+      v = s.lds[s.sp << s.shift];
+      if (WITH_T) t = __uint_as_float(s.lds[(s.sp + s.lds_cap) << s.shift]);
+    } else if (WITH_T) {
+      v = s.ovf[2 * (s.sp - s.lds_cap)];
+      t = __uint_as_float(s.ovf[2 * (s.sp - s.lds_cap) + 1]);
+    } else {
+      v = s.ovf[s.sp - s.lds_cap];
+    }
+    if (!WITH_T || t <= capf) return v;
+  }
 }
 
 // Register images of the two records the traversal reads most.
@@ -264,6 +296,70 @@ __device__ inline void load_sphere(const DScene& S, const NodeCache& C, uint32_t
   n.c[2] = u2d(b.x, b.y); n.dc[0] = u2d(b.z, b.w);
   n.dc[1] = u2d(c.x, c.y); n.dc[2] = u2d(c.z, c.w);
   n.r = u2d(d.x, d.y);
+}
+
+struct TNodeRec {
+  float l[6], r[6];
+  nref_t left, right;
+};
+template <bool CACHE>
+__device__ inline void load_tnode(const DScene& S, const NodeCache& C, uint32_t idx, TNodeRec& n) {
+  uint4 a, b, c, d;
+  if (CACHE && idx < C.n_bvh) {
+    const uint32_t i = C.bvh_off + idx;
+    a = lds_read4(i); b = lds_read4(i + C.cap_bvh); c = lds_read4(i + 2 * C.cap_bvh); d = lds_read4(i + 3 * C.cap_bvh);
+  } else {
+    const uint4* p = reinterpret_cast<const uint4*>(S.tnodes + idx);
+    a = p[0]; b = p[1]; c = p[2]; d = p[3];
+  }
+  n.l[0] = __uint_as_float(a.x); n.l[1] = __uint_as_float(a.y); n.l[2] = __uint_as_float(a.z); n.l[3] = __uint_as_float(a.w);
+  n.l[4] = __uint_as_float(b.x); n.l[5] = __uint_as_float(b.y); n.r[0] = __uint_as_float(b.z); n.r[1] = __uint_as_float(b.w);
+  n.r[2] = __uint_as_float(c.x); n.r[3] = __uint_as_float(c.y); n.r[4] = __uint_as_float(c.z); n.r[5] = __uint_as_float(c.w);
+  n.left = d.x; n.right = d.y;
+}
+
+// Conservative f32 slab test of one child box against the ray's culling form: [entry, exit] contains
+// every t in [tmin, closest] at which the ray is inside the f64 box, so a child with entry > exit can
+// hold no hit that would replace the current one.
+#define CHIP_CULL_DELTA 9.5367431640625e-07f  // 2^-20: covers the f32 rounding of 1/d, m and the multiply-add
+#define CHIP_CULL_TMIN 0.00099999f             // just below the 0.001 ray minimum of camera.rs:264
+#define CHIP_CULL_BIG 3.0e38f
+__device__ inline void cull_slab(const float* b, const TravRay& r, float& entry, float& exit) {
+  const float x0 = fmaf(b[0], r.m_lo[0], r.c_lo[0]), x1 = fmaf(b[1], r.m_hi[0], r.c_hi[0]);
+  const float y0 = fmaf(b[2], r.m_lo[1], r.c_lo[1]), y1 = fmaf(b[3], r.m_hi[1], r.c_hi[1]);
+  const float z0 = fmaf(b[4], r.m_lo[2], r.c_lo[2]), z1 = fmaf(b[5], r.m_hi[2], r.c_hi[2]);
+  entry = fmaxf(fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1)), CHIP_CULL_TMIN);
+  exit = fminf(fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)), r.capf);
+}
+__device__ inline float f32_above(double v) {  // an f32 >= v (one ulp of slack)
+  const float f = (float)v;
+  return fmaf(fabsf(f), 1.1920929e-07f, f);
+}
+__device__ inline float f32_below(double v) {
+  const float f = (float)v;
+  return fmaf(-fabsf(f), 1.1920929e-07f, f);
+}
+// Culling form for the ray currently in r.o / r.d.
+__device__ inline void ray_set_cull(TravRay& r) {
+  const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float invf = __frcp_rn((float)d[a]);
+    if (fabsf(invf) <= 1.0e18f) {
+      const bool pos = invf > 0.0f;
+      const float s = pos ? CHIP_CULL_DELTA : -CHIP_CULL_DELTA;
+      const float ml = invf * (1.0f - s), mh = invf * (1.0f + s);
+      const double cl = -(o[a] * (double)ml), ch = -(o[a] * (double)mh);
+      r.m_lo[a] = ml;
+      r.m_hi[a] = mh;
+      r.c_lo[a] = pos ? f32_below(cl) : f32_above(cl);  // the low plane is the entry plane iff d > 0
+      r.c_hi[a] = pos ? f32_above(ch) : f32_below(ch);
+    } else {  // direction component (nearly) zero: this axis does not cull
+      r.m_lo[a] = r.m_hi[a] = 0.0f;
+      r.c_lo[a] = -CHIP_CULL_BIG;
+      r.c_hi[a] = CHIP_CULL_BIG;
+    }
+  }
 }
 
 // aabb.rs:195-228.  The per-axis early return is folded into one final test: the
@@ -356,8 +452,41 @@ __device__ inline bool quad_hit(const DQuad& q, const TravRay& r, double tmin, d
   return true;
 }
 
+// Ordered traversal visits primitives in another order than the reference, so a candidate whose t
+// equals the current closest t exactly is decided by what the reference's order would have done:
+// the later primitive (depth-first position `seq`) replaces the earlier one iff its own interval test
+// is inclusive (quad.rs:152 `contains`), and loses iff it is exclusive (sphere.rs:110 `surrounds`).
+__device__ __noinline__ bool tie_wins(const DScene& S, nref_t cand, nref_t best) {
+  if (best == NREF_NONE) return true;
+  const bool cq = NREF_KIND(cand) == NK_QUAD, bq = NREF_KIND(best) == NK_QUAD;
+  const uint32_t sc = cq ? S.quads[NREF_INDEX(cand)].seq : S.spheres[NREF_INDEX(cand)].seq;
+  const uint32_t sb = bq ? S.quads[NREF_INDEX(best)].seq : S.spheres[NREF_INDEX(best)].seq;
+  return sc >= sb ? cq : !bq;
+}
+// sphere.rs:99-121 with the interval's upper end inclusive (ties are then settled by tie_wins)
+template <typename SphereT>
+__device__ inline bool sphere_hit_incl(const SphereT& s, const TravRay& r, double tmin, double tmax, double& t_out) {
+  V3 center = ld3(s.c) + (r.time * ld3(s.dc));
+  V3 oc = center - r.o;
+  double a = r.dd;
+  double h = dot(r.d, oc);
+  double c = len2(oc) - s.r * s.r;
+  double disc = h * h - a * c;
+  if (disc < 0.0) return false;
+  double sq = sqrt(disc);
+  double root = (h - sq) / a;
+  if (!(tmin < root && root <= tmax)) {
+    root = (h + sq) / a;
+    if (!(tmin < root && root <= tmax)) return false;
+  }
+  t_out = root;
+  return true;
+}
+
+template <bool ORD = false>
 __device__ inline void ray_set_inv(TravRay& r) {
-  r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+  if (ORD) ray_set_cull(r);
+  else r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
   r.dd = len2(r.d);
 }
 // translate.rs:28 / rotate.rs:137-138
@@ -392,7 +521,10 @@ enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4 };  // quads & groups
 // is exhausted.  With YIELD the loop also returns (cursor and stack intact, to be resumed) as soon as
 // fewer than CHIP_REFILL_THRESH lanes of the wave are still traversing, so the caller can hand the
 // idle lanes new rays.
-template <uint32_t F, bool YIELD, bool CACHE>
+// ORD selects the ordered traversal (nearer child first, f32 child-box culling, ties settled by the
+// reference's visiting order); without it the reference's own order and f64 box tests are interpreted
+// literally, which the ConstantMedium variant needs (its result depends on the interval it is handed).
+template <uint32_t F, bool YIELD, bool CACHE, bool ORD = !(F & TF_MEDIA)>
 __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng,
                          TravStack& st, const int base, TravCounters& cnt, bool may_yield = true);
 
@@ -402,43 +534,72 @@ __device__ __noinline__ void traverse_boundary(const DScene& S, nref_t start, Tr
                                                Rng& rng, TravStack& st, TravCounters& cnt) {
   nref_t node = start;
   NodeCache none{0, 0, 0, 0, 0, 0};
-  traverse<TF_QUADS | TF_XFORM, false, false>(S, none, node, r, tmin, best_t, best, rng, st, st.sp, cnt);
+  traverse<TF_QUADS | TF_XFORM, false, false, false>(S, none, node, r, tmin, best_t, best, rng, st, st.sp, cnt);
 }
 
-template <uint32_t F, bool YIELD, bool CACHE>
+template <uint32_t F, bool YIELD, bool CACHE, bool ORD>
 __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng,
                          TravStack& st, const int base, TravCounters& cnt, bool may_yield) {
   for (;;) {
     // BVH descent (bvh.rs:58-76): test the node's own box over (tmin, best_t); left first, right deferred.
-    while (NREF_KIND(node) == NK_BVH) {
-      BvhRec n;
-      load_bvh<CACHE>(S, C, NREF_INDEX(node), n);
-      cnt.bvh++;
-      if (aabb_hit(n.box, r, tmin, best_t)) {
-        st_push(st, n.right);
-        node = n.left;
-      } else {
-        node = st_pop(st, base);
+    if (ORD) {
+      // both child boxes are tested here; the nearer child is visited first, the other one deferred
+      while (NREF_KIND(node) == NK_BVH) {
+        TNodeRec n;
+        load_tnode<CACHE>(S, C, NREF_INDEX(node), n);
+        cnt.bvh++;
+        float el, xl, er, xr;
+        cull_slab(n.l, r, el, xl);
+        cull_slab(n.r, r, er, xr);
+        const bool hl = el <= xl, hr = er <= xr;
+        if (hl && hr) {
+          const bool swap = er < el;
+          st_push<true>(st, swap ? n.left : n.right, swap ? el : er);
+          node = swap ? n.right : n.left;
+        } else if (hl || hr) {
+          node = hl ? n.left : n.right;
+        } else {
+          node = st_pop<true>(st, base, r.capf);
+        }
+      }
+    } else {
+      while (NREF_KIND(node) == NK_BVH) {
+        BvhRec n;
+        load_bvh<CACHE>(S, C, NREF_INDEX(node), n);
+        cnt.bvh++;
+        if (aabb_hit(n.box, r, tmin, best_t)) {
+          st_push<false>(st, n.right);
+          node = n.left;
+        } else {
+          node = st_pop<false>(st, base);
+        }
       }
     }
     if (node == NREF_NONE) break;
     const uint32_t kind = NREF_KIND(node), idx = NREF_INDEX(node);
+    // candidate hit at t: closer wins; ORD settles exact ties by the reference's visiting order
+#define CHIP_TAKE(ref, tval)                                                  \
+  if (!ORD || (tval) < best_t || tie_wins(S, (ref), best)) {                  \
+    best_t = (tval);                                                          \
+    best = (ref);                                                             \
+    if (ORD) r.capf = f32_above(best_t);                                      \
+  }
     if (kind == NK_SPHERE) {
       double t;
       cnt.prim++;
       SphereRec sp;
       load_sphere<CACHE>(S, C, idx, sp);
-      if (sphere_hit(sp, r, tmin, best_t, t)) { best_t = t; best = node; }
+      if (ORD ? sphere_hit_incl(sp, r, tmin, best_t, t) : sphere_hit(sp, r, tmin, best_t, t)) { CHIP_TAKE(node, t) }
     } else if ((F & TF_QUADS) && kind == NK_QUAD) {
       double t, al, be;
       cnt.prim++;
-      if (quad_hit(S.quads[idx], r, tmin, best_t, t, al, be)) { best_t = t; best = node; }
+      if (quad_hit(S.quads[idx], r, tmin, best_t, t, al, be)) { CHIP_TAKE(node, t) }
     } else if ((F & TF_QUADS) && (kind == NK_GROUP || kind == NK_GROUP_CONT)) {
       // group.rs:44-54: children in order, each over the shrinking interval.  Primitive
       // children are tested inline; any other child is descended into, leaving a
       // (position, continuation) pair on the stack.
       uint32_t pos = 0;
-      if (kind == NK_GROUP_CONT) pos = st_pop(st, base);
+      if (kind == NK_GROUP_CONT) pos = st_pop_raw(st, base, ORD);
       const DGroup g = S.groups[idx];
       nref_t descend = NREF_NONE;
       for (; pos < g.count; pos++) {
@@ -447,15 +608,17 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
         if (ck == NK_SPHERE) {
           double t;
           cnt.prim++;
-          if (sphere_hit(S.spheres[NREF_INDEX(c)], r, tmin, best_t, t)) { best_t = t; best = c; }
+          if (ORD ? sphere_hit_incl(S.spheres[NREF_INDEX(c)], r, tmin, best_t, t) : sphere_hit(S.spheres[NREF_INDEX(c)], r, tmin, best_t, t)) {
+            CHIP_TAKE(c, t)
+          }
         } else if (ck == NK_QUAD) {
           double t, al, be;
           cnt.prim++;
-          if (quad_hit(S.quads[NREF_INDEX(c)], r, tmin, best_t, t, al, be)) { best_t = t; best = c; }
+          if (quad_hit(S.quads[NREF_INDEX(c)], r, tmin, best_t, t, al, be)) { CHIP_TAKE(c, t) }
         } else {
           if (pos + 1 < g.count) {
-            st_push(st, pos + 1);
-            st_push(st, NREF(NK_GROUP_CONT, idx));
+            st_push<ORD>(st, pos + 1);
+            st_push<ORD>(st, NREF(NK_GROUP_CONT, idx));
           }
           descend = c;
           break;
@@ -464,22 +627,23 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       if (descend != NREF_NONE) { node = descend; continue; }
     } else if ((F & TF_XFORM) && kind == NK_TRANSLATE) {
       const DTranslate& t = S.translates[idx];
-      st_push(st, NREF(NK_EXIT_TRANSLATE, idx));
+      st_push<ORD>(st, NREF(NK_EXIT_TRANSLATE, idx));
       r.o = r.o - ld3(t.off);
+      if (ORD) ray_set_cull(r);
       node = t.child;
       continue;
     } else if ((F & TF_XFORM) && kind == NK_ROTATE) {
       const DRotate& t = S.rotates[idx];
-      st_push(st, NREF(NK_EXIT_ROTATE, idx));
+      st_push<ORD>(st, NREF(NK_EXIT_ROTATE, idx));
       r.o = mat_mulT(t.m, r.o);
       r.d = mat_mulT(t.m, r.d);
-      ray_set_inv(r);
+      ray_set_inv<ORD>(r);
       node = t.child;
       continue;
     } else if ((F & TF_XFORM) && (kind == NK_EXIT_TRANSLATE || kind == NK_EXIT_ROTATE)) {
       nref_t px = kind == NK_EXIT_TRANSLATE ? S.translates[idx].parent_xform : S.rotates[idx].parent_xform;
       ray_to_space(S, px, r.wo, r.wd, r.o, r.d);
-      ray_set_inv(r);
+      ray_set_inv<ORD>(r);
     } else if ((F & TF_MEDIA) && kind == NK_MEDIUM) {
       // constant_medium.rs:41-80
       const DMedium m = S.media[idx];
@@ -504,9 +668,10 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
         }
       }
     }
-    node = st_pop(st, base);
+    node = st_pop<ORD>(st, base, r.capf);
     if (YIELD && may_yield && __popcll(__ballot(1)) < CHIP_REFILL_THRESH) break;
   }
+#undef CHIP_TAKE
 }
 
 // ------------------------------------------------------------------ fast shading arithmetic
@@ -867,12 +1032,12 @@ __host__ __device__ constexpr int extend_min_waves(uint32_t F, bool CACHE) {
 }
 template <uint32_t F, bool CACHE>
 __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CACHE)) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce, CacheDesc cd) {
-  // LDS layout: [4 x n_bvh uint4][4 x n_sph uint4][stack_entries x blockDim u32]
+  // LDS layout: [4 x n_bvh uint4][4 x n_sph uint4][stack_entries x blockDim u32 values][the same again: entry distances (ordered variants)]
   const NodeCache C{0u, 4u * cd.n_bvh, cd.n_bvh, cd.n_sph, cd.n_bvh, cd.n_sph};
   uint32_t* lds_stack = reinterpret_cast<uint32_t*>(g_lds) + 16u * (cd.n_bvh + cd.n_sph);
   if (CACHE) {
     for (uint32_t i = threadIdx.x; i < cd.n_bvh; i += blockDim.x) {
-      const uint4* p = reinterpret_cast<const uint4*>(S.bvh + i);
+      const uint4* p = (F & TF_MEDIA) ? reinterpret_cast<const uint4*>(S.bvh + i) : reinterpret_cast<const uint4*>(S.tnodes + i);
       g_lds[i] = p[0]; g_lds[cd.n_bvh + i] = p[1]; g_lds[2 * cd.n_bvh + i] = p[2]; g_lds[3 * cd.n_bvh + i] = p[3];
     }
     const uint32_t so = 4u * cd.n_bvh;
@@ -890,7 +1055,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
   const uint32_t lane = __lane_id();
   TravStack st;
   st.lds = (lds_u32_t)lds_stack + threadIdx.x;
-  st.ovf = P.ovf + (size_t)gtid * CHIP_STACK_OVF;
+  st.ovf = P.ovf + (size_t)gtid * (2 * CHIP_STACK_OVF);
   st.overflow = 0;
   st.sp = 0;
   st.lds_cap = (int)cd.stack_entries;
@@ -944,7 +1109,8 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
           slot = q_in[w_next + rank];
           ray_load(P, slot, r.wo, r.wd, r.time);
           r.o = r.wo; r.d = r.wd;
-          ray_set_inv(r);
+          ray_set_inv<!(F & TF_MEDIA)>(r);
+          r.capf = INFINITY;
           if (F & TF_MEDIA) {
             uint32_t x, y, pixel, stratum;
             slot_to_path(B, S.cam, slot, x, y, pixel, stratum);
@@ -1254,11 +1420,11 @@ struct DHitOut {
 template <uint32_t F>
 __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P, uint32_t seed_lo, uint32_t seed_hi, uint32_t n,
                                                            const double* o, const double* d, const double* tm, DHitOut* out) {
-  __shared__ uint32_t lds_stack[CHIP_STACK_LDS * CHIP_BLOCK];
+  __shared__ uint32_t lds_stack[2 * CHIP_STACK_LDS * CHIP_BLOCK];
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   TravStack st;
   st.lds = (lds_u32_t)lds_stack + threadIdx.x;
-  st.ovf = P.ovf + (size_t)gtid * CHIP_STACK_OVF;
+  st.ovf = P.ovf + (size_t)gtid * (2 * CHIP_STACK_OVF);
   st.overflow = 0;
   st.lds_cap = CHIP_STACK_LDS;
   st.shift = 31 - __clz(CHIP_BLOCK);
@@ -1270,7 +1436,8 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P,
     r.wd = mk(d[3 * (size_t)i], d[3 * (size_t)i + 1], d[3 * (size_t)i + 2]);
     r.time = tm ? tm[i] : 0.0;
     r.o = r.wo; r.d = r.wd;
-    ray_set_inv(r);
+    ray_set_inv<!(F & TF_MEDIA)>(r);
+    r.capf = INFINITY;
     Rng rng;
     rng.init(seed_lo, seed_hi, i, 0, 0, 0);
     double best_t = INFINITY;

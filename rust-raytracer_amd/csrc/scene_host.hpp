@@ -85,6 +85,8 @@ struct HNode {
 
 struct Flat {
   std::vector<DBvhNode> bvh;
+  std::vector<DTNode> tnodes;          // culling image of bvh[], same indices
+  std::vector<Box6> bvh_child_box[2];  // boxes of each BVH node's left / right child (flattening scratch)
   std::vector<DSphere> spheres;
   std::vector<DQuad> quads;
   std::vector<DGroup> groups;
@@ -337,6 +339,7 @@ struct HostScene {
   struct Flattener {
     const HostScene& H;
     Flat& F;
+    uint32_t seq = 0;  // primitives emitted so far, in the reference's depth-first visiting order
     explicit Flattener(const HostScene& h, Flat& f) : H(h), F(f) {}
 
     void chain_of(nref_t x, std::vector<nref_t>& out) const {
@@ -356,6 +359,7 @@ struct HostScene {
       s.mat = (uint32_t)n.mat;
       s.xform = xform;
       s.leaf_id = leaf_id;
+      s.seq = seq++;
       F.spheres.push_back(s);
       return NREF(NK_SPHERE, F.spheres.size() - 1);
     }
@@ -368,6 +372,7 @@ struct HostScene {
       q.mat = (uint32_t)n.mat;
       q.xform = xform;
       q.leaf_id = leaf_id;
+      q.seq = seq++;
       F.quads.push_back(q);
       return NREF(NK_QUAD, F.quads.size() - 1);
     }
@@ -395,6 +400,8 @@ struct HostScene {
         case CHIP_NODE_BVH: {
           size_t idx = F.bvh.size();
           F.bvh.push_back(DBvhNode{});
+          F.bvh_child_box[0].push_back(H.nodes[n.c0].box);
+          F.bvh_child_box[1].push_back(H.nodes[n.c1].box);
           nref_t l = emit(n.c0, xform, in_boundary, leaf_override);
           nref_t r = n.c1 == n.c0 ? l : emit(n.c1, xform, in_boundary, leaf_override);
           DBvhNode& b = F.bvh[idx];
@@ -485,6 +492,7 @@ struct HostScene {
       }
     }
     reorder_bvh_breadth_first(F);
+    build_tnodes(F);
     if (F.bvh.size() >= (1u << 28) || F.spheres.size() >= (1u << 28) || F.quads.size() >= (1u << 28))
       throw std::runtime_error("scene too large for 28-bit node indices");
   }
@@ -517,17 +525,60 @@ struct HostScene {
     for (uint32_t i = 0; i < n; i++) bfs_from(i);  // BVHs below groups / transforms / media, in table order
     auto remap = [&](nref_t r) -> nref_t { return NREF_KIND(r) == NK_BVH ? NREF(NK_BVH, newidx[NREF_INDEX(r)]) : r; };
     std::vector<DBvhNode> nb(n);
+    std::vector<Box6> cb[2] = {std::vector<Box6>(n), std::vector<Box6>(n)};
     for (size_t i = 0; i < n; i++) {
       nb[i] = F.bvh[order[i]];
       nb[i].left = remap(nb[i].left);
       nb[i].right = remap(nb[i].right);
+      cb[0][i] = F.bvh_child_box[0][order[i]];
+      cb[1][i] = F.bvh_child_box[1][order[i]];
     }
     F.bvh.swap(nb);
+    F.bvh_child_box[0].swap(cb[0]);
+    F.bvh_child_box[1].swap(cb[1]);
     F.root = remap(F.root);
     for (nref_t& c : F.gchild) c = remap(c);
     for (DTranslate& t : F.translates) t.child = remap(t.child);
     for (DRotate& t : F.rotates) t.child = remap(t.child);
     for (DMedium& m : F.media) m.boundary = remap(m.boundary);
+  }
+
+  // f32 neighbours of an f64 value, rounded away from / towards the box interior.
+  static float f32_down(double v) {
+    float f = (float)v;
+    return (double)f > v ? std::nextafterf(f, -std::numeric_limits<float>::infinity()) : f;
+  }
+  static float f32_up(double v) {
+    float f = (float)v;
+    return (double)f < v ? std::nextafterf(f, std::numeric_limits<float>::infinity()) : f;
+  }
+  // Culling boxes of every BVH node's children.  Minima round down and maxima round up, so each f32 box
+  // contains the reference's f64 box; infinities (empty boxes, aabb.rs:41-47) become +-FLT_MAX so that
+  // the device's multiply-add slab test never forms inf - inf.
+  static void build_tnodes(Flat& F) {
+    const float big = std::numeric_limits<float>::max();
+    auto clampf = [&](float v) { return v > big ? big : (v < -big ? -big : v); };
+    const size_t n = F.bvh.size();
+    F.tnodes.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      DTNode& t = F.tnodes[i];
+      std::memset(&t, 0, sizeof(t));
+      t.left = F.bvh[i].left;
+      t.right = F.bvh[i].right;
+      for (int a = 0; a < 3; a++) {
+        t.lbox[2 * a] = clampf(f32_down(F.bvh_child_box[0][i].v[2 * a]));
+        t.lbox[2 * a + 1] = clampf(f32_up(F.bvh_child_box[0][i].v[2 * a + 1]));
+        t.rbox[2 * a] = clampf(f32_down(F.bvh_child_box[1][i].v[2 * a]));
+        t.rbox[2 * a + 1] = clampf(f32_up(F.bvh_child_box[1][i].v[2 * a + 1]));
+      }
+      if (t.left == t.right) {  // one node stored twice: visit it once
+        for (int a = 0; a < 3; a++) { t.rbox[2 * a] = big; t.rbox[2 * a + 1] = -big; }
+      }
+    }
+    F.bvh_child_box[0].clear();
+    F.bvh_child_box[1].clear();
+    F.bvh_child_box[0].shrink_to_fit();
+    F.bvh_child_box[1].shrink_to_fit();
   }
 
   // Preorder dump in the order the reference's tree would be walked.
