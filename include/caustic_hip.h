@@ -91,7 +91,14 @@ enum {
    * PDFs, so a render consumes the Philox stream exactly as the f64 CPU restatement does.  The default shade
    * kernels use f32-seeded Newton reciprocals / f32 trigonometry there (same estimator, last-digit differences
    * in sampled directions).  Traversal and hit records are f64 / reference order in both modes. */
-  CHIP_RENDER_EXACT_SHADING = 2
+  CHIP_RENDER_EXACT_SHADING = 2,
+  /* Trace every ray by replaying the reference's recursion literally (bounding_volume_hierarchy.rs:58-76: own
+   * box, left, then right over the shrunken interval, f64 slab tests) instead of the default ordered traversal
+   * (nearer child first, conservative f32 culling, exact ties settled by the reference's visiting order).  The two
+   * agree except where a ray meets a bounding box exactly at the distance of a hit found earlier, which the
+   * reference's `max <= min` slab rejection (axis_aligned_bounding_box.rs:207-225) turns into a miss.  Rays with a
+   * zero direction component always take the literal path (their slab arithmetic forms NaNs). */
+  CHIP_RENDER_REFERENCE_ORDER = 4
 };
 enum { CHIP_MAT_LAMBERTIAN = 0, CHIP_MAT_METAL = 1, CHIP_MAT_DIELECTRIC = 2, CHIP_MAT_DIFFUSE_LIGHT = 3, CHIP_MAT_ISOTROPIC = 4, CHIP_MAT_EMPTY = 5 };
 /* node kinds reported by chip_dump_tree */

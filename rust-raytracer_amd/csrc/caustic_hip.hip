@@ -298,6 +298,7 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       B.n_paths = npix * B.n_strata;
       B.seed_lo = (uint32_t)o->seed;
       B.seed_hi = (uint32_t)(o->seed >> 32);
+      B.reference_order = (o->flags & CHIP_RENDER_REFERENCE_ORDER) ? 1u : 0u;
       n_paths_total += B.n_paths;
       n_batches++;
       HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)s->counters_rows * 8 * sizeof(uint32_t), stream));

@@ -60,6 +60,7 @@ struct BatchDesc {
   uint32_t stratum_first, stratum_stride;     // global stratum of batch-local sb: first + sb*stride
   uint32_t n_paths;                           // npix * n_strata
   uint32_t seed_lo, seed_hi;
+  uint32_t reference_order;                   // trace every ray in the reference's own visiting order
 };
 
 // ------------------------------------------------------------------ Philox4x32-10 stream
@@ -203,6 +204,7 @@ struct TravStack {
   uint32_t* ovf;  // this thread's global spill slab
   int sp;
   uint32_t overflow;
+  uint32_t redo;    // ordered traversal met a ray it must not handle (see traverse): rerun it literally
   int lds_cap;      // entries kept in LDS
   uint32_t shift;   // log2 of the LDS words between consecutive entries of one lane (= threads per block)
 };
@@ -521,6 +523,12 @@ enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4 };  // quads & groups
 // is exhausted.  With YIELD the loop also returns (cursor and stack intact, to be resumed) as soon as
 // fewer than CHIP_REFILL_THRESH lanes of the wave are still traversing, so the caller can hand the
 // idle lanes new rays.
+// A zero direction component makes the reference's slab test (aabb.rs:202-228) form 0 * inf = NaN when the
+// origin lies exactly on a box plane, and its compare chain then rejects or accepts the box depending on
+// the sign of the zero; the culling test of the ordered traversal does not reproduce that, so such rays
+// are traced by the literal interpretation instead.
+__device__ inline bool has_zero_component(V3 d) { return !(d.x != 0.0 && d.y != 0.0 && d.z != 0.0) || d.x != d.x || d.y != d.y || d.z != d.z; }
+
 // ORD selects the ordered traversal (nearer child first, f32 child-box culling, ties settled by the
 // reference's visiting order); without it the reference's own order and f64 box tests are interpreted
 // literally, which the ConstantMedium variant needs (its result depends on the interval it is handed).
@@ -637,6 +645,11 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       st_push<ORD>(st, NREF(NK_EXIT_ROTATE, idx));
       r.o = mat_mulT(t.m, r.o);
       r.d = mat_mulT(t.m, r.d);
+      if (ORD && has_zero_component(r.d)) {  // only an exact cancellation gets here: start over, literally
+        st.redo = 1;
+        node = NREF_NONE;
+        return;
+      }
       ray_set_inv<ORD>(r);
       node = t.child;
       continue;
@@ -1057,13 +1070,17 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
   st.lds = (lds_u32_t)lds_stack + threadIdx.x;
   st.ovf = P.ovf + (size_t)gtid * (2 * CHIP_STACK_OVF);
   st.overflow = 0;
+  st.redo = 0;
   st.sp = 0;
   st.lds_cap = (int)cd.stack_entries;
   st.shift = 31 - __clz((int)blockDim.x);
   TravCounters cnt{0, 0};
   uint32_t nseg = 0;
   const size_t cap = P.cap;
-  bool has = false;  // this lane holds a ray (traversing or finished)
+  constexpr bool ORD = !(F & TF_MEDIA);
+  const NodeCache no_cache{0, 0, 0, 0, 0, 0};
+  bool has = false;      // this lane holds a ray (traversing or finished)
+  bool literal = !ORD;   // this lane's ray is traced in the reference's own order
   uint32_t slot = 0;
   TravRay r;
   r.wo = r.wd = r.o = r.d = r.inv = mk(0, 0, 0);
@@ -1080,6 +1097,17 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
   uint32_t w_next = 0, w_end = 0;  // wave-uniform
   bool exhausted = false;
   for (;;) {
+    // 0. a ray the ordered traversal handed back starts again from the root in the reference's order
+    if (ORD && has && st.redo) {
+      st.redo = 0;
+      literal = true;
+      r.o = r.wo; r.d = r.wd;
+      ray_set_inv<false>(r);
+      best_t = INFINITY;
+      best = NREF_NONE;
+      node = S.root;
+      st.sp = 0;
+    }
     // 1. lanes whose traversal finished store (t, node); the HitRecord is rebuilt where it is consumed
     if (has && node == NREF_NONE) {
       nseg++;
@@ -1109,7 +1137,9 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
           slot = q_in[w_next + rank];
           ray_load(P, slot, r.wo, r.wd, r.time);
           r.o = r.wo; r.d = r.wd;
-          ray_set_inv<!(F & TF_MEDIA)>(r);
+          literal = !ORD || B.reference_order || has_zero_component(r.wd);
+          if (literal) ray_set_inv<false>(r);
+          else ray_set_inv<true>(r);
           r.capf = INFINITY;
           if (F & TF_MEDIA) {
             uint32_t x, y, pixel, stratum;
@@ -1127,7 +1157,14 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
     }
     if (!__any(has) && exhausted) break;
     // 3. traverse until the rays are done or too few lanes are still busy
-    if (has) traverse<F, true, CACHE>(S, C, node, r, 0.001, best_t, best, rng, st, 0, cnt, !(exhausted && w_next >= w_end));
+    const bool may_yield = !(exhausted && w_next >= w_end);
+    if constexpr (ORD) {
+      if (has && !literal) traverse<F, true, CACHE, true>(S, C, node, r, 0.001, best_t, best, rng, st, 0, cnt, may_yield);
+      if (has && literal && node != NREF_NONE && !st.redo)
+        traverse<F, true, false, false>(S, no_cache, node, r, 0.001, best_t, best, rng, st, 0, cnt, may_yield);
+    } else {
+      if (has) traverse<F, true, CACHE, false>(S, C, node, r, 0.001, best_t, best, rng, st, 0, cnt, may_yield);
+    }
   }
   if (st.overflow) atomicOr(&P.errflag[0], 1u);
   // per-wave reduction of the traversal counters
@@ -1426,6 +1463,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P,
   st.lds = (lds_u32_t)lds_stack + threadIdx.x;
   st.ovf = P.ovf + (size_t)gtid * (2 * CHIP_STACK_OVF);
   st.overflow = 0;
+  st.redo = 0;
   st.lds_cap = CHIP_STACK_LDS;
   st.shift = 31 - __clz(CHIP_BLOCK);
   const NodeCache none{0, 0, 0, 0, 0, 0};
@@ -1436,15 +1474,34 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P,
     r.wd = mk(d[3 * (size_t)i], d[3 * (size_t)i + 1], d[3 * (size_t)i + 2]);
     r.time = tm ? tm[i] : 0.0;
     r.o = r.wo; r.d = r.wd;
-    ray_set_inv<!(F & TF_MEDIA)>(r);
+    constexpr bool ORD = !(F & TF_MEDIA);
+    bool literal = !ORD || has_zero_component(r.wd);
+    if (literal) ray_set_inv<false>(r);
+    else ray_set_inv<true>(r);
     r.capf = INFINITY;
     Rng rng;
     rng.init(seed_lo, seed_hi, i, 0, 0, 0);
     double best_t = INFINITY;
     nref_t best = NREF_NONE;
     st.sp = 0;
+    st.redo = 0;
     nref_t node = S.root;
-    traverse<F, false, false>(S, none, node, r, 0.001, best_t, best, rng, st, 0, cnt);
+    if constexpr (ORD) {
+      if (!literal) traverse<F, false, false, true>(S, none, node, r, 0.001, best_t, best, rng, st, 0, cnt);
+      if (st.redo) {  // handed back by the ordered traversal: start over in the reference's order
+        st.redo = 0;
+        literal = true;
+        r.o = r.wo; r.d = r.wd;
+        ray_set_inv<false>(r);
+        best_t = INFINITY;
+        best = NREF_NONE;
+        st.sp = 0;
+        node = S.root;
+      }
+      if (literal) traverse<F, false, false, false>(S, none, node, r, 0.001, best_t, best, rng, st, 0, cnt);
+    } else {
+      traverse<F, false, false, false>(S, none, node, r, 0.001, best_t, best, rng, st, 0, cnt);
+    }
     DHitOut h;
     h.t = 0; h.u = 0; h.v = 0;
     for (int k = 0; k < 3; k++) { h.pt[k] = 0; h.normal[k] = 0; }

@@ -199,3 +199,83 @@ def test_depth_zero_and_empty_world(pkg, gpu, oracle):
         sc.commit()
         img, _, _ = sc.render_frame(seed=1, sum_dtype=np.float32 if be is gpu else np.float64)
         np.testing.assert_allclose(img / 4.0, np.broadcast_to(np.array([0.25, 0.5, 1.0]), img.shape), rtol=1e-6)
+
+
+def _tie_scene(be, variant):
+    """Primitives that produce bitwise-equal hit distances: duplicated spheres (one of each pair behind an
+    exactly representable Translate), coplanar overlapping quads, and quads tangent to spheres.  The
+    winner of such a tie depends on the order the reference visits the primitives in (group.rs:47-52,
+    bvh.rs:66-70, inclusive `contains` in quad.rs:152 against exclusive `surrounds` in sphere.rs:110)."""
+    rng = np.random.default_rng(7 + variant)
+    sc = be.new_scene()
+    lam = sc.lambertian_color(0.5, 0.5, 0.5)
+    met = sc.metal(0.8, 0.8, 0.8, 0.0)
+    die = sc.dielectric(1.5)
+    lit = sc.diffuse_light_color(1, 1, 1)
+    nodes = []
+    for k in range(24):
+        c = rng.integers(-24, 25, 3) / 4.0
+        r = float(rng.integers(2, 7)) / 4.0
+        a = sc.sphere(tuple(c), r, lam)
+        off = rng.integers(-3, 4, 3).astype(float)
+        b = sc.translate(sc.sphere(tuple(c - off), r, met), tuple(off))
+        nodes += [a, b] if k % 2 else [b, a]
+        if k % 3 == 0:  # a quad tangent to the sphere's top, and one through its centre plane
+            nodes.append(sc.quad((c[0] - 2, c[1] + r, c[2] - 2), (4, 0, 0), (0, 0, 4), die))
+    for k in range(12):
+        z = float(rng.integers(-20, 21)) / 4.0
+        x = float(rng.integers(-16, 9)) / 4.0
+        y = float(rng.integers(-16, 9)) / 4.0
+        nodes.append(sc.quad((x, y, z), (2, 0, 0), (0, 2, 0), lam))
+        nodes.append(sc.quad((x + 1, y + 0.5, z), (2, 0, 0), (0, 2, 0), lit))
+        nodes.append(sc.quad((x - 1, y - 0.5, z), (4, 0, 0), (0, 4, 0), met))
+    order = rng.permutation(len(nodes))
+    nodes = [nodes[i] for i in order]
+    if variant == 0:
+        world = sc.bvh(nodes)
+    elif variant == 1:
+        h = len(nodes) // 2
+        world = sc.bvh([sc.group(nodes[:h]), sc.bvh(nodes[h:])])
+    else:
+        world = sc.group([sc.bvh(nodes[i::3]) for i in range(3)])
+    sc.set_world(world)
+    sc.set_camera(image_width=32, samples_per_pixel=1, max_depth=2, look_from=(0, 0, 20), look_at=(0, 0, 0), background=(1, 1, 1))
+    sc.commit()
+    return sc
+
+
+def _tie_rays(n=400_000):
+    """Generic rays (no special alignment with the scene): a coplanar pair of quads or a duplicated sphere
+    still gives bitwise-equal distances, because both primitives evaluate the same expression."""
+    rng = np.random.default_rng(99)
+    o = rng.uniform(-10.0, 10.0, (n, 3))
+    target = rng.uniform(-6.0, 6.0, (n, 3))
+    d = (target - o) * rng.uniform(0.2, 3.0, (n, 1))
+    return o, d
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_exact_ties_follow_reference_order(gpu, oracle, variant):
+    """A scene full of coincident surfaces: where two primitives report the same distance, the GPU's
+    ordered traversal must name the primitive the reference's left-to-right recursion names.  (Rays that
+    touch a bounding box exactly at the distance of an earlier hit are excluded by using generic rays: the
+    reference then rejects the box with its `max <= min` test, aabb.rs:207-225, which only an exact f64
+    replay of its visiting order reproduces.)"""
+    sg, so = _tie_scene(gpu, variant), _tie_scene(oracle, variant)
+    o, d = _tie_rays()
+    hg = sg.trace_rays(o, d, None, seed=1)
+    ho = so.trace_rays(o, d, None, seed=1)
+    info = compare_hits(hg, ho)
+    print("ties", variant, info)
+    assert info["n_hit"] > 0.1 * len(o) and info["t_bit_identical"]
+
+
+@pytest.mark.parametrize("name", ["random_spheres", "cornell_box", "final"])
+def test_ordered_traversal_equals_reference_order_render(pkg, gpu, name):
+    """The default ordered traversal and the literal replay of the reference's visiting order find the
+    same (t, primitive) for every segment, so whole renders are bit-identical."""
+    sg = pkg.scenes.build(gpu, name, width=160, spp=16, depth=20)
+    a, _, sa = sg.render_frame(seed=3)
+    b, _, sb = sg.render_frame(seed=3, flags=pkg.bindings.RENDER_REFERENCE_ORDER)
+    assert sa["segments"] == sb["segments"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
