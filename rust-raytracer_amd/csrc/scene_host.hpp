@@ -87,6 +87,7 @@ struct Flat {
   std::vector<DBvhNode> bvh;
   std::vector<DTNode> tnodes;          // culling image of bvh[], same indices
   std::vector<Box6> bvh_child_box[2];  // boxes of each BVH node's left / right child (flattening scratch)
+  std::vector<uint8_t> bvh_is_root;    // node was the top of a BoundingVolumeHierarchy::new call (flattening scratch)
   std::vector<DSphere> spheres;
   std::vector<DQuad> quads;
   std::vector<DGroup> groups;
@@ -402,6 +403,7 @@ struct HostScene {
           F.bvh.push_back(DBvhNode{});
           F.bvh_child_box[0].push_back(H.nodes[n.c0].box);
           F.bvh_child_box[1].push_back(H.nodes[n.c1].box);
+          F.bvh_is_root.push_back(n.id >= 0 ? 1 : 0);
           nref_t l = emit(n.c0, xform, in_boundary, leaf_override);
           nref_t r = n.c1 == n.c0 ? l : emit(n.c1, xform, in_boundary, leaf_override);
           DBvhNode& b = F.bvh[idx];
@@ -526,7 +528,9 @@ struct HostScene {
     auto remap = [&](nref_t r) -> nref_t { return NREF_KIND(r) == NK_BVH ? NREF(NK_BVH, newidx[NREF_INDEX(r)]) : r; };
     std::vector<DBvhNode> nb(n);
     std::vector<Box6> cb[2] = {std::vector<Box6>(n), std::vector<Box6>(n)};
+    std::vector<uint8_t> ir(n);
     for (size_t i = 0; i < n; i++) {
+      ir[i] = F.bvh_is_root[order[i]];
       nb[i] = F.bvh[order[i]];
       nb[i].left = remap(nb[i].left);
       nb[i].right = remap(nb[i].right);
@@ -536,6 +540,7 @@ struct HostScene {
     F.bvh.swap(nb);
     F.bvh_child_box[0].swap(cb[0]);
     F.bvh_child_box[1].swap(cb[1]);
+    F.bvh_is_root.swap(ir);
     F.root = remap(F.root);
     for (nref_t& c : F.gchild) c = remap(c);
     for (DTranslate& t : F.translates) t.child = remap(t.child);
@@ -552,33 +557,175 @@ struct HostScene {
     float f = (float)v;
     return (double)f < v ? std::nextafterf(f, std::numeric_limits<float>::infinity()) : f;
   }
-  // Culling boxes of every BVH node's children.  Minima round down and maxima round up, so each f32 box
-  // contains the reference's f64 box; infinities (empty boxes, aabb.rs:41-47) become +-FLT_MAX so that
-  // the device's multiply-add slab test never forms inf - inf.
-  static void build_tnodes(Flat& F) {
+  // The culling trees of the ordered traversal.  Every BoundingVolumeHierarchy of the scene keeps its
+  // reference-built tree in F.bvh (that tree fixes the visiting order, hence which primitive wins an exact
+  // tie, and is what the literal traversal walks); for culling, the same member list is re-split by a binned
+  // surface-area heuristic, which is free to separate a huge member (the r = 1000 ground sphere) from the
+  // small ones instead of cutting the sorted list in half (bvh.rs:16-46).  A culling node stores the f32
+  // boxes of its two children: minima rounded down and maxima up, so each contains the reference's f64
+  // box; infinities (empty boxes, aabb.rs:41-47) become +-FLT_MAX so the device's multiply-add slab test
+  // never forms inf - inf.  The culling nodes of one hierarchy live in the table slots of that
+  // hierarchy's reference nodes (there are at least as many), root in the root's slot, top levels first.
+  struct SahLeaf {
+    nref_t ref;
+    Box6 box;
+    double c[3];
+  };
+  static double box_area(const Box6& b) {
+    double dx = b.v[1] - b.v[0], dy = b.v[3] - b.v[2], dz = b.v[5] - b.v[4];
+    if (!(dx >= 0.0) || !(dy >= 0.0) || !(dz >= 0.0)) return 0.0;
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+  }
+  static Box6 box_merge(const Box6& x, const Box6& y) {
+    Box6 b;
+    for (int a = 0; a < 3; a++) {
+      b.v[2 * a] = std::fmin(x.v[2 * a], y.v[2 * a]);
+      b.v[2 * a + 1] = std::fmax(x.v[2 * a + 1], y.v[2 * a + 1]);
+    }
+    return b;
+  }
+  static void set_cull_box(float* out, const Box6& b) {
     const float big = std::numeric_limits<float>::max();
     auto clampf = [&](float v) { return v > big ? big : (v < -big ? -big : v); };
+    for (int a = 0; a < 3; a++) {
+      out[2 * a] = clampf(f32_down(b.v[2 * a]));
+      out[2 * a + 1] = clampf(f32_up(b.v[2 * a + 1]));
+    }
+  }
+  static void set_empty_box(float* out) {
+    const float big = std::numeric_limits<float>::max();
+    for (int a = 0; a < 3; a++) { out[2 * a] = big; out[2 * a + 1] = -big; }
+  }
+  // Splits leaves[lo, hi) (hi - lo >= 2) and returns the split position.
+  static size_t sah_split(std::vector<SahLeaf>& leaves, size_t lo, size_t hi) {
+    const int kBins = 16;
+    const size_t n = hi - lo;
+    double cmin[3] = {kInf, kInf, kInf}, cmax[3] = {-kInf, -kInf, -kInf};
+    for (size_t i = lo; i < hi; i++)
+      for (int a = 0; a < 3; a++) {
+        cmin[a] = std::fmin(cmin[a], leaves[i].c[a]);
+        cmax[a] = std::fmax(cmax[a], leaves[i].c[a]);
+      }
+    double best_cost = kInf;
+    int best_axis = -1, best_bin = -1;
+    for (int a = 0; a < 3; a++) {
+      const double ext = cmax[a] - cmin[a];
+      if (!(ext > 0.0) || !std::isfinite(ext)) continue;
+      Box6 bb[kBins];
+      size_t cnt[kBins] = {0};
+      const Box6 none{{kInf, -kInf, kInf, -kInf, kInf, -kInf}};
+      for (int k = 0; k < kBins; k++) bb[k] = none;
+      const double scale = kBins / ext;
+      for (size_t i = lo; i < hi; i++) {
+        int k = (int)((leaves[i].c[a] - cmin[a]) * scale);
+        k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+        bb[k] = box_merge(bb[k], leaves[i].box);
+        cnt[k]++;
+      }
+      double right_area[kBins];
+      size_t right_cnt[kBins];
+      Box6 acc = none;
+      size_t c = 0;
+      for (int k = kBins - 1; k > 0; k--) {
+        acc = box_merge(acc, bb[k]);
+        c += cnt[k];
+        right_area[k] = box_area(acc);
+        right_cnt[k] = c;
+      }
+      acc = none;
+      c = 0;
+      for (int k = 0; k + 1 < kBins; k++) {
+        acc = box_merge(acc, bb[k]);
+        c += cnt[k];
+        if (c == 0 || right_cnt[k + 1] == 0) continue;
+        double cost = box_area(acc) * (double)c + right_area[k + 1] * (double)right_cnt[k + 1];
+        if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+      }
+    }
+    if (best_axis < 0) return lo + n / 2;  // coincident centroids: any split will do
+    const double ext = cmax[best_axis] - cmin[best_axis];
+    const double scale = kBins / ext;
+    auto mid = std::partition(leaves.begin() + lo, leaves.begin() + hi, [&](const SahLeaf& l) {
+      int k = (int)((l.c[best_axis] - cmin[best_axis]) * scale);
+      k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+      return k <= best_bin;
+    });
+    size_t m = (size_t)(mid - leaves.begin());
+    return (m == lo || m == hi) ? lo + n / 2 : m;
+  }
+  static void build_tnodes(Flat& F) {
     const size_t n = F.bvh.size();
     F.tnodes.resize(n);
     for (size_t i = 0; i < n; i++) {
       DTNode& t = F.tnodes[i];
       std::memset(&t, 0, sizeof(t));
-      t.left = F.bvh[i].left;
-      t.right = F.bvh[i].right;
-      for (int a = 0; a < 3; a++) {
-        t.lbox[2 * a] = clampf(f32_down(F.bvh_child_box[0][i].v[2 * a]));
-        t.lbox[2 * a + 1] = clampf(f32_up(F.bvh_child_box[0][i].v[2 * a + 1]));
-        t.rbox[2 * a] = clampf(f32_down(F.bvh_child_box[1][i].v[2 * a]));
-        t.rbox[2 * a + 1] = clampf(f32_up(F.bvh_child_box[1][i].v[2 * a + 1]));
+      t.left = t.right = NREF_NONE;
+      set_empty_box(t.lbox);
+      set_empty_box(t.rbox);
+    }
+    std::vector<SahLeaf> leaves;
+    std::vector<uint32_t> slots, stack;
+    struct Job { size_t lo, hi; uint32_t slot; };
+    std::vector<Job> queue;
+    for (size_t root = 0; root < n; root++) {
+      if (!F.bvh_is_root[root]) continue;
+      // members and table slots of this hierarchy: walk its reference nodes
+      leaves.clear();
+      slots.clear();
+      stack.assign(1, (uint32_t)root);
+      while (!stack.empty()) {
+        uint32_t i = stack.back();
+        stack.pop_back();
+        slots.push_back(i);
+        const DBvhNode& b = F.bvh[i];
+        for (int side = 0; side < 2; side++) {
+          nref_t c = side == 0 ? b.left : b.right;
+          if (side == 1 && b.right == b.left) break;  // a single member is stored twice (bvh.rs:27-28)
+          if (NREF_KIND(c) == NK_BVH && !F.bvh_is_root[NREF_INDEX(c)]) { stack.push_back(NREF_INDEX(c)); continue; }
+          SahLeaf l;
+          l.ref = c;
+          l.box = F.bvh_child_box[side][i];
+          for (int a = 0; a < 3; a++) l.c[a] = 0.5 * (l.box.v[2 * a] + l.box.v[2 * a + 1]);
+          leaves.push_back(l);
+        }
       }
-      if (t.left == t.right) {  // one node stored twice: visit it once
-        for (int a = 0; a < 3; a++) { t.rbox[2 * a] = big; t.rbox[2 * a + 1] = -big; }
+      std::sort(slots.begin(), slots.end());
+      // drop members with an empty box (the two empty Groups of an empty hierarchy, bvh.rs:23-26)
+      leaves.erase(std::remove_if(leaves.begin(), leaves.end(), [](const SahLeaf& l) { return !(l.box.v[0] <= l.box.v[1]); }), leaves.end());
+      if (leaves.empty()) continue;
+      if (leaves.size() == 1) {
+        DTNode& t = F.tnodes[root];
+        t.left = leaves[0].ref;
+        set_cull_box(t.lbox, leaves[0].box);
+        continue;
+      }
+      // breadth-first construction; node k of this hierarchy takes the k-th smallest slot
+      queue.clear();
+      queue.push_back(Job{0, leaves.size(), slots[0]});
+      size_t next_slot = 1;
+      for (size_t q = 0; q < queue.size(); q++) {
+        const Job job = queue[q];
+        const size_t mid = sah_split(leaves, job.lo, job.hi);
+        DTNode& t = F.tnodes[job.slot];
+        for (int side = 0; side < 2; side++) {
+          const size_t lo = side == 0 ? job.lo : mid, hi = side == 0 ? mid : job.hi;
+          Box6 bb = leaves[lo].box;
+          for (size_t i = lo + 1; i < hi; i++) bb = box_merge(bb, leaves[i].box);
+          nref_t ref;
+          if (hi - lo == 1) {
+            ref = leaves[lo].ref;
+          } else {
+            const uint32_t slot = slots[next_slot++];
+            ref = NREF(NK_BVH, slot);
+            queue.push_back(Job{lo, hi, slot});
+          }
+          if (side == 0) { t.left = ref; set_cull_box(t.lbox, bb); }
+          else { t.right = ref; set_cull_box(t.rbox, bb); }
+        }
       }
     }
-    F.bvh_child_box[0].clear();
-    F.bvh_child_box[1].clear();
-    F.bvh_child_box[0].shrink_to_fit();
-    F.bvh_child_box[1].shrink_to_fit();
+    for (int k = 0; k < 2; k++) { F.bvh_child_box[k].clear(); F.bvh_child_box[k].shrink_to_fit(); }
+    F.bvh_is_root.clear();
   }
 
   // Preorder dump in the order the reference's tree would be walked.

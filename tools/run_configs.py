@@ -36,14 +36,14 @@ for a in args:
     if a == "rtiow":
         run("S2 RTIOW final 1920x1080", lambda: pkg.scenes.build(gpu, "random_spheres", width=1920, spp=64, depth=50), "64 of 1024 spp")
     elif a == "final":
-        run("S3 Next-Week final 800x800", lambda: pkg.scenes.build(gpu, "final", width=800, spp=100, depth=40), "100 of 10000 spp")
+        run("S3 Next-Week final 800x800", lambda: pkg.scenes.build(gpu, "final", width=800, spp=400, depth=40), "400 of 10000 spp")
     elif a == "cornell":
-        run("S4 Cornell box 600x600", lambda: pkg.scenes.build(gpu, "cornell_box", width=600, spp=256, depth=50), "256 of 4096 spp")
+        run("S4 Cornell box 600x600", lambda: pkg.scenes.build(gpu, "cornell_box", width=600, spp=729, depth=50), "729 of 4096 spp")
     elif a.startswith("lattice"):
         n = int(a.split(":")[1]) if ":" in a else 100
         def b():
             sc = gpu.new_scene()
-            pkg.scenes.scad_lattice(sc, n=n, width=1920, spp=16, depth=50)
+            pkg.scenes.scad_lattice(sc, n=n, width=1920, spp=64, depth=50)
             sc.commit()
             return sc
-        run(f"S5 scad-shaped lattice {n}^3 1920x1080", b, "16 of 256 spp")
+        run(f"S5 scad-shaped lattice {n}^3 1920x1080", b, "64 of 256 spp")
