@@ -78,7 +78,7 @@ struct chip_scene {
   DevBuf<PathHit> p_hit;
   DevBuf<PathMap> p_st;
   DevBuf<float4> p_sample;
-  DevBuf<uint32_t> p_qlive0, p_qlive1, p_qmat, p_counters, p_err, p_ovf;
+  DevBuf<uint32_t> p_qlive0, p_qlive1, p_qmat, p_qlit, p_counters, p_err, p_ovf;
   DevBuf<unsigned long long> p_stats;
   uint32_t counters_rows = 0;
   uint32_t* h_pinned = nullptr;
@@ -88,7 +88,7 @@ struct chip_scene {
     d_translates.release(); d_rotates.release(); d_media.release(); d_xchain.release(); d_materials.release();
     d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
     p_ray.release(); p_hit.release(); p_st.release(); p_sample.release();
-    p_qlive0.release(); p_qlive1.release(); p_qmat.release(); p_counters.release(); p_err.release(); p_ovf.release();
+    p_qlive0.release(); p_qlive1.release(); p_qmat.release(); p_qlit.release(); p_counters.release(); p_err.release(); p_ovf.release();
     p_stats.release();
     if (h_pinned) (void)hipHostFree(h_pinned);
     h_pinned = nullptr;
@@ -119,7 +119,7 @@ static size_t pool_capacity_max() {
   }
   return (size_t)1 << 28;
 }
-static const size_t kBytesPerPathSlot = sizeof(PathRay) + sizeof(PathHit) + sizeof(PathMap) + sizeof(float4) + sizeof(uint32_t) * (2 + MK_COUNT);
+static const size_t kBytesPerPathSlot = sizeof(PathRay) + sizeof(PathHit) + sizeof(PathMap) + sizeof(float4) + sizeof(uint32_t) * (3 + MK_COUNT);
 
 // Makes the pool hold min(want_paths, the maximum above, what fits in free device memory) path slots.
 static int ensure_pool(chip_scene* s, size_t want_paths) {
@@ -140,7 +140,7 @@ static int ensure_pool(chip_scene* s, size_t want_paths) {
   }
   if (!s->pool_ready || s->pool.cap < cap) {
     s->p_ray.release(); s->p_hit.release(); s->p_st.release(); s->p_sample.release();
-    s->p_qlive0.release(); s->p_qlive1.release(); s->p_qmat.release();
+    s->p_qlive0.release(); s->p_qlive1.release(); s->p_qmat.release(); s->p_qlit.release();
     HIP_TRY(s->p_ray.alloc(cap));
     HIP_TRY(s->p_hit.alloc(cap));
     HIP_TRY(s->p_st.alloc(cap));
@@ -148,15 +148,16 @@ static int ensure_pool(chip_scene* s, size_t want_paths) {
     HIP_TRY(s->p_qlive0.alloc(cap));
     HIP_TRY(s->p_qlive1.alloc(cap));
     HIP_TRY(s->p_qmat.alloc((size_t)MK_COUNT * cap));
+    HIP_TRY(s->p_qlit.alloc(cap));
     s->pool.cap = (uint32_t)cap;
   }
   if (s->counters_rows < rows) {
-    HIP_TRY(s->p_counters.alloc((size_t)rows * 8));
+    HIP_TRY(s->p_counters.alloc((size_t)rows * CHIP_CTR_STRIDE));
     s->counters_rows = rows;
   }
   PathPool& P = s->pool;
   P.ray = s->p_ray.p; P.hit = s->p_hit.p; P.st = s->p_st.p; P.sample = s->p_sample.p;
-  P.q_live[0] = s->p_qlive0.p; P.q_live[1] = s->p_qlive1.p; P.q_mat = s->p_qmat.p;
+  P.q_live[0] = s->p_qlive0.p; P.q_live[1] = s->p_qlive1.p; P.q_mat = s->p_qmat.p; P.q_lit = s->p_qlit.p;
   P.counters = s->p_counters.p; P.errflag = s->p_err.p; P.stats = s->p_stats.p; P.ovf = s->p_ovf.p;
   s->pool_ready = true;
   return 0;
@@ -201,10 +202,11 @@ struct ExtendPlan {
   uint32_t block, lds_bytes;
 };
 static const uint32_t kLdsBytes = 160 * 1024;
-static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat) {
+// uncached: the plain 256-thread form (literal passes)
+static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached) {
   ExtendPlan p;
   const char* e = getenv("CHIP_NO_LDS_CACHE");
-  p.cache = !s->flat.bvh.empty() && !(e && *e == '1');
+  p.cache = !uncached && !s->flat.bvh.empty() && !(e && *e == '1');
   if (p.cache) {
     p.block = (feat & TF_MEDIA) ? 512 : 1024;
     const bool ordered = !(feat & TF_MEDIA);  // ordered variants keep an entry distance beside every stack value
@@ -222,36 +224,56 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat) {
   }
   return p;
 }
-template <uint32_t F, bool CACHE>
-static void launch_extend_t(const chip_scene* s, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce) {
+template <uint32_t F, bool CACHE, bool ORD>
+static void launch_extend_t(const chip_scene* s, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce,
+                            uint32_t lit_pass) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_extend<F, CACHE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    (void)hipFuncSetAttribute((const void*)k_extend<F, CACHE, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     attr_set = true;
   }
   uint32_t blocks = (n_live_upper + p.block - 1) / p.block;
   uint32_t max_blocks = CACHE ? (uint32_t)s->n_cus : kMaxGridBlocksDef;
   blocks = std::max(1u, std::min(blocks, max_blocks));
-  hipLaunchKernelGGL((k_extend<F, CACHE>), dim3(blocks), dim3(p.block), p.lds_bytes, st, s->dscene, s->pool, B, bounce, p.cd);
+  hipLaunchKernelGGL((k_extend<F, CACHE, ORD>), dim3(blocks), dim3(p.block), p.lds_bytes, st, s->dscene, s->pool, B, bounce, p.cd, lit_pass);
 }
+// One bounce of traversal.  ConstantMedium scenes and reference_order renders replay the reference's order for
+// every ray; everything else runs the ordered traversal followed by a (normally empty) literal pass over the
+// rays it handed back.
 static void launch_extend(const chip_scene* s, uint32_t feat, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce) {
-  const ExtendPlan p = plan_extend(s, feat);
-#define CHIP_EXT(FEAT)                                                                 \
-  if (p.cache) launch_extend_t<FEAT, true>(s, p, n_live_upper, st, B, bounce);         \
-  else launch_extend_t<FEAT, false>(s, p, n_live_upper, st, B, bounce)
+  if (feat & TF_MEDIA) {
+    const ExtendPlan p = plan_extend(s, feat, false);
+    if (p.cache) launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, true, false>(s, p, n_live_upper, st, B, bounce, 0);
+    else launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, false, false>(s, p, n_live_upper, st, B, bounce, 0);
+    return;
+  }
+  const ExtendPlan lit = plan_extend(s, feat, true);
+  const ExtendPlan p = plan_extend(s, feat, false);
+#define CHIP_EXT(FEAT)                                                                                    \
+  if (B.reference_order) {                                                                                \
+    launch_extend_t<FEAT, false, false>(s, lit, n_live_upper, st, B, bounce, 0);                          \
+  } else {                                                                                                \
+    if (p.cache) launch_extend_t<FEAT, true, true>(s, p, n_live_upper, st, B, bounce, 0);                 \
+    else launch_extend_t<FEAT, false, true>(s, p, n_live_upper, st, B, bounce, 0);                        \
+    launch_extend_t<FEAT, false, false>(s, lit, std::min<uint32_t>(n_live_upper, 64u * CHIP_BLOCK), st, B, bounce, 1); \
+  }
   switch (feat) {
     case 0: CHIP_EXT(0); break;
     case TF_QUADS: CHIP_EXT(TF_QUADS); break;
-    case TF_QUADS | TF_XFORM: CHIP_EXT(TF_QUADS | TF_XFORM); break;
-    default: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA); break;
+    default: CHIP_EXT(TF_QUADS | TF_XFORM); break;
   }
 #undef CHIP_EXT
 }
 
 template <uint32_t K>
-static void launch_shade(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, uint32_t grid, hipStream_t st, bool exact) {
-  if (exact) hipLaunchKernelGGL((k_shade<K, false>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
-  else hipLaunchKernelGGL((k_shade<K, true>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
+static void launch_shade(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, uint32_t grid, hipStream_t st, bool exact, bool lean) {
+  if (lean) {
+    if (exact) hipLaunchKernelGGL((k_shade<K, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
+    else hipLaunchKernelGGL((k_shade<K, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
+  } else {
+    if (exact) hipLaunchKernelGGL((k_shade<K, false, false>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
+    else hipLaunchKernelGGL((k_shade<K, true, false>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
+  }
 }
 
 // Adds the rectangle's radiance sums for the planned strata into d_sum (device, rw*rh*3 floats).
@@ -265,7 +287,10 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
   const bool exact_shading = (o->flags & CHIP_RENDER_EXACT_SHADING) != 0;
   const uint32_t feat = scene_features(s->flat);
   uint32_t mat_mask = 0;
-  for (const DMaterial& m : s->host.materials) mat_mask |= 1u << m.kind;  // scenes lacking a node family run a leaner traversal variant
+  for (const DMaterial& m : s->host.materials) mat_mask |= 1u << m.kind;
+  // spheres with solid colours and no light sampling: the lean shade kernels
+  bool lean = feat == 0 && !s->flat.has_lights;
+  for (const DTexture& t : s->host.textures) lean = lean && t.kind == TK_SOLID;
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0));
   HIP_TRY(hipEventCreate(&ev1));
@@ -301,8 +326,10 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       B.reference_order = (o->flags & CHIP_RENDER_REFERENCE_ORDER) ? 1u : 0u;
       n_paths_total += B.n_paths;
       n_batches++;
-      HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)s->counters_rows * 8 * sizeof(uint32_t), stream));
+      HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)s->counters_rows * CHIP_CTR_STRIDE * sizeof(uint32_t), stream));
       hipLaunchKernelGGL(k_raygen, dim3(grid_for(B.n_paths)), dim3(CHIP_BLOCK), 0, stream, S, P, B);
+      // a path writes its sample when it ends; with max_depth 0 no path ever starts (camera.rs:259-261)
+      if (cam.max_depth == 0) HIP_TRY(hipMemsetAsync(P.sample, 0, (size_t)B.n_paths * sizeof(float4), stream));
       uint32_t live_upper = B.n_paths;
       for (uint32_t bounce = 0; bounce < cam.max_depth; bounce++) {
         uint32_t grid = grid_for(live_upper);
@@ -310,18 +337,20 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
         launch_extend(s, feat, live_upper, stream, B, bounce);
         if (time_kernels) (void)hipEventRecord(new_event(), stream);
         n_trace_launches++;
-        hipLaunchKernelGGL(k_bin, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, bounce, (uint32_t)((feat & TF_MEDIA) != 0));
-        // only the material kinds the scene contains can have queue entries
-        if (mat_mask & (1u << MK_LAMBERTIAN)) launch_shade<MK_LAMBERTIAN>(S, P, B, bounce, grid, stream, exact_shading);
-        if (mat_mask & (1u << MK_METAL)) launch_shade<MK_METAL>(S, P, B, bounce, grid, stream, exact_shading);
-        if (mat_mask & (1u << MK_DIELECTRIC)) launch_shade<MK_DIELECTRIC>(S, P, B, bounce, grid, stream, exact_shading);
-        if (mat_mask & (1u << MK_DIFFUSE_LIGHT)) launch_shade<MK_DIFFUSE_LIGHT>(S, P, B, bounce, grid, stream, exact_shading);
-        if (mat_mask & (1u << MK_ISOTROPIC)) launch_shade<MK_ISOTROPIC>(S, P, B, bounce, grid, stream, exact_shading);
-        if (mat_mask & (1u << MK_EMPTY)) launch_shade<MK_EMPTY>(S, P, B, bounce, grid, stream, exact_shading);
+        {
+          hipLaunchKernelGGL(k_bin, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, bounce, (uint32_t)((feat & TF_MEDIA) != 0));
+          // only the material kinds the scene contains can have queue entries
+          if (mat_mask & (1u << MK_LAMBERTIAN)) launch_shade<MK_LAMBERTIAN>(S, P, B, bounce, grid, stream, exact_shading, lean);
+          if (mat_mask & (1u << MK_METAL)) launch_shade<MK_METAL>(S, P, B, bounce, grid, stream, exact_shading, lean);
+          if (mat_mask & (1u << MK_DIELECTRIC)) launch_shade<MK_DIELECTRIC>(S, P, B, bounce, grid, stream, exact_shading, lean);
+          if (mat_mask & (1u << MK_DIFFUSE_LIGHT)) launch_shade<MK_DIFFUSE_LIGHT>(S, P, B, bounce, grid, stream, exact_shading, lean);
+          if (mat_mask & (1u << MK_ISOTROPIC)) launch_shade<MK_ISOTROPIC>(S, P, B, bounce, grid, stream, exact_shading, lean);
+          if (mat_mask & (1u << MK_EMPTY)) launch_shade<MK_EMPTY>(S, P, B, bounce, grid, stream, exact_shading, lean);
+        }
         if (time_kernels) (void)hipEventRecord(new_event(), stream);
         // every few bounces learn how many paths are still alive (stops the loop early)
         if (bounce + 1 < cam.max_depth && (bounce % 4) == 3) {
-          HIP_TRY(hipMemcpyAsync(s->h_pinned, P.counters + (size_t)(bounce + 1) * 8, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+          HIP_TRY(hipMemcpyAsync(s->h_pinned, P.counters + (size_t)(bounce + 1) * CHIP_CTR_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
           HIP_TRY(hipStreamSynchronize(stream));
           live_upper = s->h_pinned[0];
           if (live_upper == 0) break;

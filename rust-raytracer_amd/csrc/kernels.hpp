@@ -21,6 +21,12 @@
 #define CHIP_TILE 2048  // queue entries a block compacts locally before one global append
 #define CHIP_PI 3.14159265358979323846
 #define CHIP_BIG 1e30f
+// Per-bounce counter row: [0] live paths, [1 .. MK_COUNT] material queue lengths, then the cursors the
+// persistent traversal waves reserve queue chunks through and the literal queue's length.
+#define CHIP_CTR_STRIDE 16
+#define CHIP_CTR_CURSOR 7
+#define CHIP_CTR_LIT 8
+#define CHIP_CTR_LIT_CURSOR 9
 
 // ------------------------------------------------------------------ path pool
 // After the first bounce the live paths are a sparse subset of the slots, so every kernel reads and
@@ -46,6 +52,7 @@ struct PathPool {
   float4* sample;   // [cap] finished sample radiance (rgb, w unused)
   uint32_t* q_live[2];  // [cap] live path slots, ping-pong per bounce
   uint32_t* q_mat;      // [MK_COUNT][cap] per-material-kind shade queues
+  uint32_t* q_lit;      // [cap] paths whose current ray the literal traversal must trace
   uint32_t* counters;   // [max_depth+2][8]: [b][0] live entering bounce b, [b][1..6] material queue sizes, [b][7] live-queue cursor
   uint32_t* errflag;    // [4]: [0] traversal stack overflow
   unsigned long long* stats;  // [4]: segments, bvh visits, prim tests, spare
@@ -934,6 +941,15 @@ __device__ inline void affine_load(const PathPool& P, uint32_t slot, Affine& f) 
   f.b[1] = v1.x; f.b[2] = v1.y; f.lo[0] = v1.z; f.lo[1] = v1.w;
   f.lo[2] = v2.x; f.hi[0] = v2.y; f.hi[1] = v2.z; f.hi[2] = v2.w;
 }
+// The map of a path that has not bounced yet is the identity and is not stored.
+__device__ inline void affine_load_at(const PathPool& P, uint32_t slot, uint32_t bounce, Affine& f) {
+  if (bounce == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { f.a[c] = 0.f; f.b[c] = 1.f; f.lo[c] = -CHIP_BIG; f.hi[c] = CHIP_BIG; }
+  } else {
+    affine_load(P, slot, f);
+  }
+}
 __device__ inline void affine_store(const PathPool& P, uint32_t slot, const Affine& f) {
   float4* p = reinterpret_cast<float4*>(P.st + slot);
   p[0] = make_float4(f.a[0], f.a[1], f.a[2], f.b[0]);
@@ -1016,20 +1032,19 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_raygen(DScene S, PathPool P, Bat
     camera_ray(S.cam, rng, x, y, stratum % S.cam.sqrt_spp, stratum / S.cam.sqrt_spp, o, d, time);
     ray_store_od(P, slot, o, d);
     reinterpret_cast<double2*>(P.ray + slot)[3] = make_double2(time, 0.0);
-    Affine f;
-#pragma unroll
-    for (int c = 0; c < 3; c++) { f.a[c] = 0.f; f.b[c] = 1.f; f.lo[c] = -CHIP_BIG; f.hi[c] = CHIP_BIG; }
-    affine_store(P, slot, f);
-    P.sample[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the radiance map starts as the identity, which bounce 0 assumes without reading it; every path
+    // writes its sample exactly once when it ends
     P.q_live[0][slot] = slot;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[0] = B.n_paths;
 }
 
 // One world.hit (camera.rs:264) per live path: closest-hit traversal; stores (t, node) per path.
-// Waves are persistent: lanes pull path slots from the bounce's live queue through a shared cursor
-// (counters[bounce][7]) and a wave refills its idle lanes whenever too few are still traversing, so
-// short rays do not leave lanes idle while long rays finish.
+// Waves are persistent: they reserve chunks of the bounce's live queue through a shared cursor.
+// ORD instantiations run the ordered traversal and hand the rays it does not take (zero direction
+// component) to the literal queue; the !ORD instantiations replay the reference's order, either for the
+// whole live queue (ConstantMedium scenes, CHIP_RENDER_REFERENCE_ORDER) or, with lit_pass, for that
+// literal queue.
 #ifndef CHIP_EXTEND_WAVES
 #define CHIP_EXTEND_WAVES 4
 #endif
@@ -1043,14 +1058,18 @@ __host__ __device__ constexpr int extend_block(uint32_t F, bool CACHE) { return 
 __host__ __device__ constexpr int extend_min_waves(uint32_t F, bool CACHE) {
   return CACHE ? 1 : ((F & TF_MEDIA) ? 1 : ((F & TF_XFORM) ? 2 : CHIP_EXTEND_WAVES));
 }
-template <uint32_t F, bool CACHE>
-__global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CACHE)) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce, CacheDesc cd) {
-  // LDS layout: [4 x n_bvh uint4][4 x n_sph uint4][stack_entries x blockDim u32 values][the same again: entry distances (ordered variants)]
+template <uint32_t F, bool CACHE, bool ORD>
+__global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CACHE)) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce, CacheDesc cd, uint32_t lit_pass) {
+  static_assert(!(ORD && (F & TF_MEDIA)), "ConstantMedium scenes are traced in the reference's order");
+  // LDS layout: [4 x n_bvh uint4][4 x n_sph uint4][stack_entries x blockDim u32 values][the same again: entry distances (ORD)]
   const NodeCache C{0u, 4u * cd.n_bvh, cd.n_bvh, cd.n_sph, cd.n_bvh, cd.n_sph};
   uint32_t* lds_stack = reinterpret_cast<uint32_t*>(g_lds) + 16u * (cd.n_bvh + cd.n_sph);
+  uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
+  const uint32_t n_live = lit_pass ? ctr[CHIP_CTR_LIT] : ctr[0];
+  if (n_live == 0) return;
   if (CACHE) {
     for (uint32_t i = threadIdx.x; i < cd.n_bvh; i += blockDim.x) {
-      const uint4* p = (F & TF_MEDIA) ? reinterpret_cast<const uint4*>(S.bvh + i) : reinterpret_cast<const uint4*>(S.tnodes + i);
+      const uint4* p = ORD ? reinterpret_cast<const uint4*>(S.tnodes + i) : reinterpret_cast<const uint4*>(S.bvh + i);
       g_lds[i] = p[0]; g_lds[cd.n_bvh + i] = p[1]; g_lds[2 * cd.n_bvh + i] = p[2]; g_lds[3 * cd.n_bvh + i] = p[3];
     }
     const uint32_t so = 4u * cd.n_bvh;
@@ -1060,10 +1079,8 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
     }
     __syncthreads();
   }
-  const uint32_t* q_in = P.q_live[bounce & 1];
-  uint32_t* ctr = P.counters + (size_t)bounce * 8;
-  const uint32_t n_live = ctr[0];
-  uint32_t* cursor = &ctr[7];
+  const uint32_t* q_in = lit_pass ? P.q_lit : P.q_live[bounce & 1];
+  uint32_t* cursor = lit_pass ? &ctr[CHIP_CTR_LIT_CURSOR] : &ctr[CHIP_CTR_CURSOR];
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = __lane_id();
   TravStack st;
@@ -1076,11 +1093,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
   st.shift = 31 - __clz((int)blockDim.x);
   TravCounters cnt{0, 0};
   uint32_t nseg = 0;
-  const size_t cap = P.cap;
-  constexpr bool ORD = !(F & TF_MEDIA);
-  const NodeCache no_cache{0, 0, 0, 0, 0, 0};
-  bool has = false;      // this lane holds a ray (traversing or finished)
-  bool literal = !ORD;   // this lane's ray is traced in the reference's own order
+  bool has = false;  // this lane holds a ray (traversing or finished)
   uint32_t slot = 0;
   TravRay r;
   r.wo = r.wd = r.o = r.d = r.inv = mk(0, 0, 0);
@@ -1089,7 +1102,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
   nref_t best = NREF_NONE, node = NREF_NONE;
   Rng rng;
   rng.init(B.seed_lo, B.seed_hi, 0, 0, bounce, 0);
-  // chunk of the live queue a wave reserves at a time: large enough to keep the shared cursor cold,
+  // chunk of the queue a wave reserves at a time: large enough to keep the shared cursor cold,
   // small enough to leave every wave of the grid some work
   const uint32_t n_waves = gridDim.x * (blockDim.x / 64);
   uint32_t chunk = (n_live / (n_waves * 4u)) & ~63u;
@@ -1097,28 +1110,22 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
   uint32_t w_next = 0, w_end = 0;  // wave-uniform
   bool exhausted = false;
   for (;;) {
-    // 0. a ray the ordered traversal handed back starts again from the root in the reference's order
-    if (ORD && has && st.redo) {
-      st.redo = 0;
-      literal = true;
-      r.o = r.wo; r.d = r.wd;
-      ray_set_inv<false>(r);
-      best_t = INFINITY;
-      best = NREF_NONE;
-      node = S.root;
-      st.sp = 0;
-    }
     // 1. lanes whose traversal finished store (t, node); the HitRecord is rebuilt where it is consumed
     if (has && node == NREF_NONE) {
-      nseg++;
-      PathHit ph;
-      ph.t = best_t;
-      ph.node = best;
-      ph.draw = (F & TF_MEDIA) ? rng.draw : 0u;
-      *reinterpret_cast<uint4*>(P.hit + slot) = *reinterpret_cast<const uint4*>(&ph);
+      if (ORD && st.redo) {  // handed back by the ordered traversal: goes to the literal queue instead
+        st.redo = 0;
+        P.q_lit[atomicAdd(&ctr[CHIP_CTR_LIT], 1u)] = slot;
+      } else {
+        nseg++;
+        PathHit ph;
+        ph.t = best_t;
+        ph.node = best;
+        ph.draw = (F & TF_MEDIA) ? rng.draw : 0u;
+        *reinterpret_cast<uint4*>(P.hit + slot) = *reinterpret_cast<const uint4*>(&ph);
+      }
       has = false;
     }
-    // 2. idle lanes take the next entries of the wave's current chunk of the live queue; a new chunk is
+    // 2. idle lanes take the next entries of the wave's current chunk of the queue; a new chunk is
     //    reserved from the shared cursor (one atomic per chunk) when the current one is used up
     {
       const unsigned long long need = __ballot(!has);
@@ -1136,35 +1143,30 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
         if (!has && rank < avail) {
           slot = q_in[w_next + rank];
           ray_load(P, slot, r.wo, r.wd, r.time);
-          r.o = r.wo; r.d = r.wd;
-          literal = !ORD || B.reference_order || has_zero_component(r.wd);
-          if (literal) ray_set_inv<false>(r);
-          else ray_set_inv<true>(r);
-          r.capf = INFINITY;
-          if (F & TF_MEDIA) {
-            uint32_t x, y, pixel, stratum;
-            slot_to_path(B, S.cam, slot, x, y, pixel, stratum);
-            rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, 0);
+          if (ORD && has_zero_component(r.wd)) {
+            P.q_lit[atomicAdd(&ctr[CHIP_CTR_LIT], 1u)] = slot;
+          } else {
+            r.o = r.wo; r.d = r.wd;
+            ray_set_inv<ORD>(r);
+            r.capf = INFINITY;
+            if (F & TF_MEDIA) {
+              uint32_t x, y, pixel, stratum;
+              slot_to_path(B, S.cam, slot, x, y, pixel, stratum);
+              rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, 0);
+            }
+            best_t = INFINITY;
+            best = NREF_NONE;
+            node = S.root;
+            st.sp = 0;
+            has = true;
           }
-          best_t = INFINITY;
-          best = NREF_NONE;
-          node = S.root;
-          st.sp = 0;
-          has = true;
         }
         w_next += min((uint32_t)__popcll(need), avail);
       }
     }
     if (!__any(has) && exhausted) break;
     // 3. traverse until the rays are done or too few lanes are still busy
-    const bool may_yield = !(exhausted && w_next >= w_end);
-    if constexpr (ORD) {
-      if (has && !literal) traverse<F, true, CACHE, true>(S, C, node, r, 0.001, best_t, best, rng, st, 0, cnt, may_yield);
-      if (has && literal && node != NREF_NONE && !st.redo)
-        traverse<F, true, false, false>(S, no_cache, node, r, 0.001, best_t, best, rng, st, 0, cnt, may_yield);
-    } else {
-      if (has) traverse<F, true, CACHE, false>(S, C, node, r, 0.001, best_t, best, rng, st, 0, cnt, may_yield);
-    }
+    if (has) traverse<F, true, CACHE, ORD>(S, C, node, r, 0.001, best_t, best, rng, st, 0, cnt, !(exhausted && w_next >= w_end));
   }
   if (st.overflow) atomicOr(&P.errflag[0], 1u);
   // per-wave reduction of the traversal counters
@@ -1198,7 +1200,7 @@ __device__ inline uint32_t node_material(const DScene& S, nref_t leaf) {
 // its output ranges with one global atomic per material kind.
 __global__ void __launch_bounds__(CHIP_BLOCK) k_bin(DScene S, PathPool P, uint32_t bounce, uint32_t has_media) {
   const uint32_t* q_in = P.q_live[bounce & 1];
-  uint32_t* ctr = P.counters + (size_t)bounce * 8;
+  uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
   const uint32_t n_live = ctr[0];
   const size_t cap = P.cap;
   __shared__ uint32_t s_slot[CHIP_TILE];
@@ -1216,13 +1218,13 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_bin(DScene S, PathPool P, uint32
       uint32_t kind = MK_COUNT;
       if (best == NREF_NONE) {
         Affine f;
-        affine_load(P, slot, f);
+        affine_load_at(P, slot, bounce, f);
         float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
         finish_path(P, slot, f, bg);
       } else {
         kind = S.materials[node_material(S, best)].kind;
-        s_rank[k] = (uint16_t)atomicAdd(&s_cnt[kind], 1u);
       }
+      if (kind < MK_COUNT) s_rank[k] = (uint16_t)atomicAdd(&s_cnt[kind], 1u);
       s_slot[k] = slot;
       s_kind[k] = (uint8_t)kind;
     }
@@ -1237,16 +1239,163 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_bin(DScene S, PathPool P, uint32
   }
 }
 
-// Material-binned shade: Material::emitted / scatter / scattering_pdf plus the PDF branch of
-// camera.rs:278-305 for one material kind.
-template <uint32_t KIND, bool FAST>
+// One hit of one path: Material::emitted / scatter / scattering_pdf of material kind KIND plus the PDF
+// branch of camera.rs:278-305.  The segment's ray (ro, rd, rtime) and closest hit (ph) come from the
+// caller; the path's radiance map is updated, the next ray stored and true returned if the path goes on,
+// otherwise the path's sample is written.
+// LEAN is the variant for scenes made only of spheres with solid-colour textures and no lights (no
+// transforms, quads, media, image / noise / checker textures or light sampling to carry in registers).
+template <uint32_t KIND, bool FAST, bool LEAN>
+__device__ inline bool shade_hit(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, bool last_bounce, uint32_t slot,
+                                 const PathHit& ph, V3 ro, V3 rd, double rtime) {
+  bool cont = false;
+  Affine f;
+  affine_load_at(P, slot, bounce, f);
+  // HitRecord of the segment's closest hit (object/mod.rs:31-51), rebuilt from (ray, t, node)
+  const nref_t leaf = ph.node;
+  const DMaterial& M = S.materials[LEAN ? S.spheres[NREF_INDEX(leaf)].mat : node_material(S, leaf)];
+  const bool has_lights = !LEAN && S.has_lights;
+  HitOut hrec;
+  reconstruct<LEAN ? 0u : (TF_QUADS | TF_XFORM | TF_MEDIA), FAST>(S, leaf, ph.t, ro, rd, rtime, hrec, !LEAN && (M.flags & MF_NEEDS_UV) != 0);
+  const bool front = hrec.front;
+  const V3 pt = hrec.pt;
+  if (KIND == MK_DIFFUSE_LIGHT) {
+    // diffuse_light.rs:28-43: no scatter; emits on the front face only
+    float x[3] = {0.f, 0.f, 0.f};
+    if (front) {
+      V3 e = tex_value(S, M.tex, hrec.u, hrec.v, pt);
+      x[0] = (float)e.x; x[1] = (float)e.y; x[2] = (float)e.z;
+    }
+    finish_path(P, slot, f, x);
+  } else if (KIND == MK_EMPTY) {
+    float x[3] = {0.f, 0.f, 0.f};  // empty.rs:18-27 + default emitted
+    finish_path(P, slot, f, x);
+  } else {
+    const V3 nrm = hrec.n;
+    uint32_t x_, y_, pixel, stratum;
+    slot_to_path(B, S.cam, slot, x_, y_, pixel, stratum);
+    Rng rng;
+    rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, ph.draw);
+    V3 ndir;
+    bool terminal = false;
+    float e[3] = {0.f, 0.f, 0.f}, w[3];
+    float klo = -CHIP_BIG, khi = CHIP_BIG;
+    if (KIND == MK_METAL) {  // metal.rs:20-28
+      V3 reflected = reflect(rd, nrm);
+      ndir = (FAST ? fast_unit(reflected) : unit(reflected)) + (M.p[3] * random_unit<FAST>(rng));
+      w[0] = (float)M.p[0]; w[1] = (float)M.p[1]; w[2] = (float)M.p[2];
+    } else if (KIND == MK_DIELECTRIC) {  // dielectric.rs:30-52
+      double ri = front ? 1.0 / M.p[0] : M.p[0];
+      V3 ud = FAST ? fast_unit(rd) : unit(rd);
+      double cos_theta = fmin(dot(-ud, nrm), 1.0);
+      double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+      bool cannot_refract = ri * sin_theta > 1.0;
+      bool refl = cannot_refract;
+      if (!refl) {
+        double r0 = (1.0 - ri) / (1.0 + ri);
+        r0 = r0 * r0;
+        double x1 = 1.0 - cos_theta;
+        double x2 = x1 * x1;
+        double x4 = x2 * x2;
+        double reflectance = r0 + (1.0 - r0) * (x4 * x1);
+        refl = reflectance > rng.next();
+      }
+      ndir = refl ? reflect(ud, nrm) : refract(ud, nrm, ri);
+      w[0] = 1.f; w[1] = 1.f; w[2] = 1.f;
+    } else {
+      // Lambertian (lambertian.rs:29-49) / Isotropic (isotropic.rs:29-44): PDF branch, camera.rs:278-305
+      V3 atten = LEAN ? ld3(S.textures[M.tex].p) : tex_value(S, M.tex, hrec.u, hrec.v, pt);  // solid_color.rs:14-17
+      bool use_light = false;
+      if (has_lights) use_light = rng.next() < 0.5;  // mixture.rs:26-32
+      if (FAST) {
+        // same estimator with the fast arithmetic above; the hit normal is already unit length
+        V3 ow = nrm, ou = nrm, ov = nrm;
+        double local_z = 0.0;
+        if (KIND == MK_LAMBERTIAN) {
+          V3 a = fabs(ow.x) > 0.9 ? mk(0.0, 1.0, 0.0) : mk(1.0, 0.0, 0.0);
+          ov = fast_unit(cross(ow, a));
+          ou = cross(ow, ov);
+        }
+        if (use_light) {
+          ndir = lights_random(S, pt, rng);
+        } else if (KIND == MK_LAMBERTIAN) {
+          float r1 = (float)rng.next(), r2 = (float)rng.next();
+          float sn, cs;
+          sincospif(2.0f * r1, &sn, &cs);
+          float sq = sqrtf(r2);
+          local_z = (double)sqrtf(1.0f - r2);
+          ndir = ((double)(cs * sq) * ou) + ((double)(sn * sq) * ov) + (local_z * ow);
+        } else {
+          ndir = random_unit<true>(rng);
+        }
+        double cos_n = 0.0;  // cosine between the scattered direction and the normal
+        if (KIND == MK_LAMBERTIAN) cos_n = (use_light || has_lights) ? dot(fast_unit(ndir), ow) : local_z;
+        double mat_pdf = KIND == MK_LAMBERTIAN ? fmax(cos_n * (1.0 / CHIP_PI), 0.0) : 1.0 / (4.0 * CHIP_PI);
+        double pv = mat_pdf;
+        if (has_lights) pv = 0.5 * lights_pdf(S, pt, ndir) + 0.5 * mat_pdf;
+        if (pv < 0.05) {
+          terminal = true;
+        } else {
+          double sp = KIND == MK_LAMBERTIAN ? (cos_n < 0.0 ? 0.0 : cos_n * (1.0 / CHIP_PI)) : 1.0 / (4.0 / CHIP_PI);
+          double k = (KIND == MK_LAMBERTIAN && !has_lights) ? 1.0 : sp * fast_rcp(pv);  // cosine sampling alone: sp == pv
+          w[0] = (float)(atten.x * k); w[1] = (float)(atten.y * k); w[2] = (float)(atten.z * k);
+          klo = 0.f; khi = 10.f;
+        }
+      } else {
+      Onb uvw(nrm);                                    // cosine.rs:10-14 (unused for Isotropic)
+      if (use_light) ndir = lights_random(S, pt, rng);
+      else if (KIND == MK_LAMBERTIAN) ndir = uvw.local(random_cosine_direction(rng));  // cosine.rs:24-27
+      else ndir = random_unit<false>(rng);                                            // probability_density_function/sphere.rs:24-26
+      double mat_pdf;
+      if (KIND == MK_LAMBERTIAN) mat_pdf = fmax(dot(unit(ndir), uvw.w) / CHIP_PI, 0.0);  // cosine.rs:18-22
+      else mat_pdf = 1.0 / (4.0 * CHIP_PI);                                              // sphere.rs:20-22
+      double pv = mat_pdf;
+      if (has_lights) {  // mixture.rs:20-24
+        double v0 = 0.5 * lights_pdf(S, pt, ndir);
+        double v1 = 0.5 * mat_pdf;
+        pv = v0 + v1;
+      }
+      if (pv < 0.05) {  // camera.rs:291-293: returns the emission (zero for these materials)
+        terminal = true;
+      } else {
+        double sp;
+        if (KIND == MK_LAMBERTIAN) {
+          double cos_theta = dot(nrm, unit(ndir));
+          sp = cos_theta < 0.0 ? 0.0 : cos_theta / CHIP_PI;
+        } else {
+          sp = 1.0 / (4.0 / CHIP_PI);  // isotropic.rs:43
+        }
+        w[0] = (float)(atten.x * sp / pv); w[1] = (float)(atten.y * sp / pv); w[2] = (float)(atten.z * sp / pv);
+        klo = 0.f; khi = 10.f;  // camera.rs:304
+      }
+      }
+    }
+    if (terminal) {
+      float x[3] = {0.f, 0.f, 0.f};
+      finish_path(P, slot, f, x);
+    } else {
+      affine_compose(f, e, w, klo, khi);
+      if (last_bounce) {
+        float x[3] = {0.f, 0.f, 0.f};  // camera.rs:259-261
+        finish_path(P, slot, f, x);
+      } else {
+        affine_store(P, slot, f);
+        ray_store_od(P, slot, pt, ndir);  // the time of the path's rays never changes (camera.rs:287)
+        cont = true;
+      }
+    }
+  }
+  return cont;
+}
+
+// Material-binned shade: the hits of one material kind, taken from that kind's queue.
+template <uint32_t KIND, bool FAST, bool LEAN>
 __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, BatchDesc B, uint32_t bounce) {
-  uint32_t* ctr = P.counters + (size_t)bounce * 8;
-  uint32_t* ctr_next = P.counters + (size_t)(bounce + 1) * 8;
+  uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
+  uint32_t* ctr_next = P.counters + (size_t)(bounce + 1) * CHIP_CTR_STRIDE;
   const uint32_t n = ctr[1 + KIND];
   const uint32_t* q = P.q_mat + (size_t)KIND * P.cap;
   uint32_t* q_out = P.q_live[(bounce + 1) & 1];
-  const size_t cap = P.cap;
   const bool last_bounce = bounce + 1 >= S.cam.max_depth;
   // A block takes tiles of CHIP_TILE queue entries; surviving paths are compacted in LDS and appended
   // to the next bounce's live queue with one global atomic per tile.
@@ -1254,166 +1403,28 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, Batc
   __shared__ uint32_t s_cnt, s_base;
   const uint32_t tile = tile_size(n, gridDim.x);
   for (uint32_t tile0 = blockIdx.x * tile; tile0 < n; tile0 += gridDim.x * tile) {
-   if (threadIdx.x == 0) s_cnt = 0;
-   __syncthreads();
-   const uint32_t tile_end = min(tile0 + tile, n);
-   for (uint32_t i = tile0 + threadIdx.x; i < tile_end; i += CHIP_BLOCK) {
-    bool cont = false;
-    uint32_t slot = 0;
-    {
-      slot = q[i];
-      Affine f;
-      affine_load(P, slot, f);
-      // HitRecord of the segment's closest hit (object/mod.rs:31-51), rebuilt from (ray, t, node)
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint32_t tile_end = min(tile0 + tile, n);
+    for (uint32_t i = tile0 + threadIdx.x; i < tile_end; i += CHIP_BLOCK) {
+      const uint32_t slot = q[i];
       PathHit ph;
       *reinterpret_cast<uint4*>(&ph) = *reinterpret_cast<const uint4*>(P.hit + slot);
-      const nref_t leaf = ph.node;
-      const DMaterial& M = S.materials[node_material(S, leaf)];
       V3 ro, rd;
       double rtime;
       ray_load(P, slot, ro, rd, rtime);
-      HitOut hrec;
-      reconstruct<TF_QUADS | TF_XFORM | TF_MEDIA, FAST>(S, leaf, ph.t, ro, rd, rtime, hrec, (M.flags & MF_NEEDS_UV) != 0);
-      const bool front = hrec.front;
-      const V3 pt = hrec.pt;
-      if (KIND == MK_DIFFUSE_LIGHT) {
-        // diffuse_light.rs:28-43: no scatter; emits on the front face only
-        float x[3] = {0.f, 0.f, 0.f};
-        if (front) {
-          V3 e = tex_value(S, M.tex, hrec.u, hrec.v, pt);
-          x[0] = (float)e.x; x[1] = (float)e.y; x[2] = (float)e.z;
-        }
-        finish_path(P, slot, f, x);
-      } else if (KIND == MK_EMPTY) {
-        float x[3] = {0.f, 0.f, 0.f};  // empty.rs:18-27 + default emitted
-        finish_path(P, slot, f, x);
-      } else {
-        const V3 nrm = hrec.n;
-        uint32_t x_, y_, pixel, stratum;
-        slot_to_path(B, S.cam, slot, x_, y_, pixel, stratum);
-        Rng rng;
-        rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, ph.draw);
-        V3 ndir;
-        bool terminal = false;
-        float e[3] = {0.f, 0.f, 0.f}, w[3];
-        float klo = -CHIP_BIG, khi = CHIP_BIG;
-        if (KIND == MK_METAL) {  // metal.rs:20-28
-          V3 reflected = reflect(rd, nrm);
-          ndir = (FAST ? fast_unit(reflected) : unit(reflected)) + (M.p[3] * random_unit<FAST>(rng));
-          w[0] = (float)M.p[0]; w[1] = (float)M.p[1]; w[2] = (float)M.p[2];
-        } else if (KIND == MK_DIELECTRIC) {  // dielectric.rs:30-52
-          double ri = front ? 1.0 / M.p[0] : M.p[0];
-          V3 ud = FAST ? fast_unit(rd) : unit(rd);
-          double cos_theta = fmin(dot(-ud, nrm), 1.0);
-          double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-          bool cannot_refract = ri * sin_theta > 1.0;
-          bool refl = cannot_refract;
-          if (!refl) {
-            double r0 = (1.0 - ri) / (1.0 + ri);
-            r0 = r0 * r0;
-            double x1 = 1.0 - cos_theta;
-            double x2 = x1 * x1;
-            double x4 = x2 * x2;
-            double reflectance = r0 + (1.0 - r0) * (x4 * x1);
-            refl = reflectance > rng.next();
-          }
-          ndir = refl ? reflect(ud, nrm) : refract(ud, nrm, ri);
-          w[0] = 1.f; w[1] = 1.f; w[2] = 1.f;
-        } else {
-          // Lambertian (lambertian.rs:29-49) / Isotropic (isotropic.rs:29-44): PDF branch, camera.rs:278-305
-          V3 atten = tex_value(S, M.tex, hrec.u, hrec.v, pt);
-          bool use_light = false;
-          if (S.has_lights) use_light = rng.next() < 0.5;  // mixture.rs:26-32
-          if (FAST) {
-            // same estimator with the fast arithmetic above; the hit normal is already unit length
-            V3 ow = nrm, ou = nrm, ov = nrm;
-            double local_z = 0.0;
-            if (KIND == MK_LAMBERTIAN) {
-              V3 a = fabs(ow.x) > 0.9 ? mk(0.0, 1.0, 0.0) : mk(1.0, 0.0, 0.0);
-              ov = fast_unit(cross(ow, a));
-              ou = cross(ow, ov);
-            }
-            if (use_light) {
-              ndir = lights_random(S, pt, rng);
-            } else if (KIND == MK_LAMBERTIAN) {
-              float r1 = (float)rng.next(), r2 = (float)rng.next();
-              float sn, cs;
-              sincospif(2.0f * r1, &sn, &cs);
-              float sq = sqrtf(r2);
-              local_z = (double)sqrtf(1.0f - r2);
-              ndir = ((double)(cs * sq) * ou) + ((double)(sn * sq) * ov) + (local_z * ow);
-            } else {
-              ndir = random_unit<true>(rng);
-            }
-            double cos_n = 0.0;  // cosine between the scattered direction and the normal
-            if (KIND == MK_LAMBERTIAN) cos_n = (use_light || S.has_lights) ? dot(fast_unit(ndir), ow) : local_z;
-            double mat_pdf = KIND == MK_LAMBERTIAN ? fmax(cos_n * (1.0 / CHIP_PI), 0.0) : 1.0 / (4.0 * CHIP_PI);
-            double pv = mat_pdf;
-            if (S.has_lights) pv = 0.5 * lights_pdf(S, pt, ndir) + 0.5 * mat_pdf;
-            if (pv < 0.05) {
-              terminal = true;
-            } else {
-              double sp = KIND == MK_LAMBERTIAN ? (cos_n < 0.0 ? 0.0 : cos_n * (1.0 / CHIP_PI)) : 1.0 / (4.0 / CHIP_PI);
-              double k = (KIND == MK_LAMBERTIAN && !S.has_lights) ? 1.0 : sp * fast_rcp(pv);  // cosine sampling alone: sp == pv
-              w[0] = (float)(atten.x * k); w[1] = (float)(atten.y * k); w[2] = (float)(atten.z * k);
-              klo = 0.f; khi = 10.f;
-            }
-          } else {
-          Onb uvw(nrm);                                    // cosine.rs:10-14 (unused for Isotropic)
-          if (use_light) ndir = lights_random(S, pt, rng);
-          else if (KIND == MK_LAMBERTIAN) ndir = uvw.local(random_cosine_direction(rng));  // cosine.rs:24-27
-          else ndir = random_unit<false>(rng);                                            // probability_density_function/sphere.rs:24-26
-          double mat_pdf;
-          if (KIND == MK_LAMBERTIAN) mat_pdf = fmax(dot(unit(ndir), uvw.w) / CHIP_PI, 0.0);  // cosine.rs:18-22
-          else mat_pdf = 1.0 / (4.0 * CHIP_PI);                                              // sphere.rs:20-22
-          double pv = mat_pdf;
-          if (S.has_lights) {  // mixture.rs:20-24
-            double v0 = 0.5 * lights_pdf(S, pt, ndir);
-            double v1 = 0.5 * mat_pdf;
-            pv = v0 + v1;
-          }
-          if (pv < 0.05) {  // camera.rs:291-293: returns the emission (zero for these materials)
-            terminal = true;
-          } else {
-            double sp;
-            if (KIND == MK_LAMBERTIAN) {
-              double cos_theta = dot(nrm, unit(ndir));
-              sp = cos_theta < 0.0 ? 0.0 : cos_theta / CHIP_PI;
-            } else {
-              sp = 1.0 / (4.0 / CHIP_PI);  // isotropic.rs:43
-            }
-            w[0] = (float)(atten.x * sp / pv); w[1] = (float)(atten.y * sp / pv); w[2] = (float)(atten.z * sp / pv);
-            klo = 0.f; khi = 10.f;  // camera.rs:304
-          }
-          }
-        }
-        if (terminal) {
-          float x[3] = {0.f, 0.f, 0.f};
-          finish_path(P, slot, f, x);
-        } else {
-          affine_compose(f, e, w, klo, khi);
-          if (last_bounce) {
-            float x[3] = {0.f, 0.f, 0.f};  // camera.rs:259-261
-            finish_path(P, slot, f, x);
-          } else {
-            affine_store(P, slot, f);
-            ray_store_od(P, slot, pt, ndir);  // the time of the path's rays never changes (camera.rs:287)
-            cont = true;
-          }
-        }
+      const bool cont = shade_hit<KIND, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime);
+      if (KIND != MK_DIFFUSE_LIGHT && KIND != MK_EMPTY) {
+        if (cont) s_pend[atomicAdd(&s_cnt, 1u)] = slot;
       }
     }
     if (KIND != MK_DIFFUSE_LIGHT && KIND != MK_EMPTY) {
-      if (cont) s_pend[atomicAdd(&s_cnt, 1u)] = slot;
+      __syncthreads();
+      if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&ctr_next[0], s_cnt) : 0u;
+      __syncthreads();
+      for (uint32_t k = threadIdx.x; k < s_cnt; k += CHIP_BLOCK) q_out[s_base + k] = s_pend[k];
     }
-   }
-   if (KIND != MK_DIFFUSE_LIGHT && KIND != MK_EMPTY) {
-     __syncthreads();
-     if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&ctr_next[0], s_cnt) : 0u;
-     __syncthreads();
-     for (uint32_t k = threadIdx.x; k < s_cnt; k += CHIP_BLOCK) q_out[s_base + k] = s_pend[k];
-   }
-   __syncthreads();
+    __syncthreads();
   }
 }
 
