@@ -71,28 +71,46 @@ struct chip_scene {
   DevBuf<uint8_t> d_texels;
   DevBuf<DLight> d_lights;
   DScene dscene;
-  // path pool
-  bool pool_ready = false;
-  PathPool pool;
-  DevBuf<PathRay> p_ray;
-  DevBuf<PathHit> p_hit;
-  DevBuf<PathMap> p_st;
-  DevBuf<float4> p_sample;
-  DevBuf<uint32_t> p_qlive0, p_qlive1, p_qmat, p_qlit, p_counters, p_err, p_ovf;
+  // Path pools.  A render of several batches runs two batches at a time, each in its own pool on its own
+  // stream, so that one batch's traversal (VALU-bound) overlaps the other's shading (HBM-bound).
+  struct PoolBufs {
+    bool ready = false;
+    PathPool P{};
+    DevBuf<PathRay> ray;
+    DevBuf<PathHit> hit;
+    DevBuf<PathMap> st;
+    DevBuf<float4> sample;
+    DevBuf<uint32_t> qlive0, qlive1, qmat, qlit, counters, ovf;
+    uint32_t counters_rows = 0;
+    uint32_t* h_live = nullptr;  // pinned: live-count readback
+    hipStream_t stream = nullptr;
+    void release() {
+      ray.release(); hit.release(); st.release(); sample.release();
+      qlive0.release(); qlive1.release(); qmat.release(); qlit.release(); counters.release(); ovf.release();
+      if (h_live) (void)hipHostFree(h_live);
+      h_live = nullptr;
+      if (stream) (void)hipStreamDestroy(stream);
+      stream = nullptr;
+      ready = false;
+      counters_rows = 0;
+      P = PathPool{};
+    }
+  };
+  PoolBufs pools[2];
+  DevBuf<uint32_t> p_err;
   DevBuf<unsigned long long> p_stats;
-  uint32_t counters_rows = 0;
   uint32_t* h_pinned = nullptr;
 
   void release_device() {
     d_bvh.release(); d_tnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release();
     d_translates.release(); d_rotates.release(); d_media.release(); d_xchain.release(); d_materials.release();
     d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
-    p_ray.release(); p_hit.release(); p_st.release(); p_sample.release();
-    p_qlive0.release(); p_qlive1.release(); p_qmat.release(); p_qlit.release(); p_counters.release(); p_err.release(); p_ovf.release();
+    pools[0].release();
+    pools[1].release();
+    p_err.release();
     p_stats.release();
     if (h_pinned) (void)hipHostFree(h_pinned);
     h_pinned = nullptr;
-    pool_ready = false;
     committed = false;
   }
 };
@@ -121,45 +139,50 @@ static size_t pool_capacity_max() {
 }
 static const size_t kBytesPerPathSlot = sizeof(PathRay) + sizeof(PathHit) + sizeof(PathMap) + sizeof(float4) + sizeof(uint32_t) * (3 + MK_COUNT);
 
-// Makes the pool hold min(want_paths, the maximum above, what fits in free device memory) path slots.
-static int ensure_pool(chip_scene* s, size_t want_paths) {
+// Makes pool `which` hold min(want_paths, max_paths, what fits in free device memory) path slots.
+static int ensure_pool(chip_scene* s, int which, size_t want_paths, size_t max_paths) {
+  chip_scene::PoolBufs& pb = s->pools[which];
   uint32_t rows = s->host.cam.max_depth + 2;
-  size_t cap = std::min(std::max<size_t>(want_paths, 4096), pool_capacity_max());
-  if (!(s->pool_ready && s->pool.cap >= cap)) {
+  size_t cap = std::min(std::max<size_t>(want_paths, 4096), std::max<size_t>(max_paths, 4096));
+  if (!(pb.ready && pb.P.cap >= cap)) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    if (s->pool_ready) free_b += (size_t)s->pool.cap * kBytesPerPathSlot;
+    if (pb.ready) free_b += (size_t)pb.P.cap * kBytesPerPathSlot;
     cap = std::min(cap, std::max<size_t>(4096, (size_t)(0.8 * (double)free_b) / kBytesPerPathSlot));
   }
-  if (s->pool_ready && s->pool.cap >= cap && s->counters_rows >= rows) return 0;
-  if (!s->pool_ready) {
+  if (!s->h_pinned) {
     HIP_TRY(s->p_err.alloc(4));
     HIP_TRY(s->p_stats.alloc(4));
-    HIP_TRY(s->p_ovf.alloc((size_t)kMaxGridBlocks * CHIP_BLOCK * CHIP_STACK_OVF * 2));
     HIP_TRY(hipHostMalloc((void**)&s->h_pinned, 64 * sizeof(uint32_t), hipHostMallocDefault));
   }
-  if (!s->pool_ready || s->pool.cap < cap) {
-    s->p_ray.release(); s->p_hit.release(); s->p_st.release(); s->p_sample.release();
-    s->p_qlive0.release(); s->p_qlive1.release(); s->p_qmat.release(); s->p_qlit.release();
-    HIP_TRY(s->p_ray.alloc(cap));
-    HIP_TRY(s->p_hit.alloc(cap));
-    HIP_TRY(s->p_st.alloc(cap));
-    HIP_TRY(s->p_sample.alloc(cap));
-    HIP_TRY(s->p_qlive0.alloc(cap));
-    HIP_TRY(s->p_qlive1.alloc(cap));
-    HIP_TRY(s->p_qmat.alloc((size_t)MK_COUNT * cap));
-    HIP_TRY(s->p_qlit.alloc(cap));
-    s->pool.cap = (uint32_t)cap;
+  if (pb.ready && pb.P.cap >= cap && pb.counters_rows >= rows) return 0;
+  if (!pb.ready) {
+    HIP_TRY(pb.ovf.alloc((size_t)kMaxGridBlocks * CHIP_BLOCK * CHIP_STACK_OVF * 2));
+    HIP_TRY(hipHostMalloc((void**)&pb.h_live, 16 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipStreamCreateWithFlags(&pb.stream, hipStreamNonBlocking));
   }
-  if (s->counters_rows < rows) {
-    HIP_TRY(s->p_counters.alloc((size_t)rows * CHIP_CTR_STRIDE));
-    s->counters_rows = rows;
+  if (!pb.ready || pb.P.cap < cap) {
+    pb.ray.release(); pb.hit.release(); pb.st.release(); pb.sample.release();
+    pb.qlive0.release(); pb.qlive1.release(); pb.qmat.release(); pb.qlit.release();
+    HIP_TRY(pb.ray.alloc(cap));
+    HIP_TRY(pb.hit.alloc(cap));
+    HIP_TRY(pb.st.alloc(cap));
+    HIP_TRY(pb.sample.alloc(cap));
+    HIP_TRY(pb.qlive0.alloc(cap));
+    HIP_TRY(pb.qlive1.alloc(cap));
+    HIP_TRY(pb.qmat.alloc((size_t)MK_COUNT * cap));
+    HIP_TRY(pb.qlit.alloc(cap));
+    pb.P.cap = (uint32_t)cap;
   }
-  PathPool& P = s->pool;
-  P.ray = s->p_ray.p; P.hit = s->p_hit.p; P.st = s->p_st.p; P.sample = s->p_sample.p;
-  P.q_live[0] = s->p_qlive0.p; P.q_live[1] = s->p_qlive1.p; P.q_mat = s->p_qmat.p; P.q_lit = s->p_qlit.p;
-  P.counters = s->p_counters.p; P.errflag = s->p_err.p; P.stats = s->p_stats.p; P.ovf = s->p_ovf.p;
-  s->pool_ready = true;
+  if (pb.counters_rows < rows) {
+    HIP_TRY(pb.counters.alloc((size_t)rows * CHIP_CTR_STRIDE));
+    pb.counters_rows = rows;
+  }
+  PathPool& P = pb.P;
+  P.ray = pb.ray.p; P.hit = pb.hit.p; P.st = pb.st.p; P.sample = pb.sample.p;
+  P.q_live[0] = pb.qlive0.p; P.q_live[1] = pb.qlive1.p; P.q_mat = pb.qmat.p; P.q_lit = pb.qlit.p;
+  P.counters = pb.counters.p; P.errflag = s->p_err.p; P.stats = s->p_stats.p; P.ovf = pb.ovf.p;
+  pb.ready = true;
   return 0;
 }
 
@@ -210,7 +233,8 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
   if (p.cache) {
     p.block = (feat & TF_MEDIA) ? 512 : 1024;
     const bool ordered = !(feat & TF_MEDIA);  // ordered variants keep an entry distance beside every stack value
-    p.cd.stack_entries = ordered ? 10 : 12;
+    p.cd.stack_entries = ordered ? 6 : 12;
+    if (const char* es = getenv("CHIP_LDS_STACK")) { int v = atoi(es); if (v >= 2 && v <= 16) p.cd.stack_entries = (uint32_t)v; }
     uint32_t stack_bytes = p.cd.stack_entries * (ordered ? 8 : 4) * p.block;
     uint32_t budget = (kLdsBytes - stack_bytes) / 64;
     p.cd.n_bvh = (uint32_t)std::min<size_t>(s->flat.bvh.size(), budget);
@@ -225,8 +249,8 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
   return p;
 }
 template <uint32_t F, bool CACHE, bool ORD>
-static void launch_extend_t(const chip_scene* s, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce,
-                            uint32_t lit_pass) {
+static void launch_extend_t(const chip_scene* s, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
+                            uint32_t bounce, uint32_t lit_pass) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_extend<F, CACHE, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
@@ -235,27 +259,27 @@ static void launch_extend_t(const chip_scene* s, const ExtendPlan& p, uint32_t n
   uint32_t blocks = (n_live_upper + p.block - 1) / p.block;
   uint32_t max_blocks = CACHE ? (uint32_t)s->n_cus : kMaxGridBlocksDef;
   blocks = std::max(1u, std::min(blocks, max_blocks));
-  hipLaunchKernelGGL((k_extend<F, CACHE, ORD>), dim3(blocks), dim3(p.block), p.lds_bytes, st, s->dscene, s->pool, B, bounce, p.cd, lit_pass);
+  hipLaunchKernelGGL((k_extend<F, CACHE, ORD>), dim3(blocks), dim3(p.block), p.lds_bytes, st, s->dscene, P, B, bounce, p.cd, lit_pass);
 }
 // One bounce of traversal.  ConstantMedium scenes and reference_order renders replay the reference's order for
 // every ray; everything else runs the ordered traversal followed by a (normally empty) literal pass over the
 // rays it handed back.
-static void launch_extend(const chip_scene* s, uint32_t feat, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce) {
+static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce) {
   if (feat & TF_MEDIA) {
     const ExtendPlan p = plan_extend(s, feat, false);
-    if (p.cache) launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, true, false>(s, p, n_live_upper, st, B, bounce, 0);
-    else launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, false, false>(s, p, n_live_upper, st, B, bounce, 0);
+    if (p.cache) launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, true, false>(s, P, p, n_live_upper, st, B, bounce, 0);
+    else launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, false, false>(s, P, p, n_live_upper, st, B, bounce, 0);
     return;
   }
   const ExtendPlan lit = plan_extend(s, feat, true);
   const ExtendPlan p = plan_extend(s, feat, false);
 #define CHIP_EXT(FEAT)                                                                                    \
   if (B.reference_order) {                                                                                \
-    launch_extend_t<FEAT, false, false>(s, lit, n_live_upper, st, B, bounce, 0);                          \
+    launch_extend_t<FEAT, false, false>(s, P, lit, n_live_upper, st, B, bounce, 0);                          \
   } else {                                                                                                \
-    if (p.cache) launch_extend_t<FEAT, true, true>(s, p, n_live_upper, st, B, bounce, 0);                 \
-    else launch_extend_t<FEAT, false, true>(s, p, n_live_upper, st, B, bounce, 0);                        \
-    launch_extend_t<FEAT, false, false>(s, lit, std::min<uint32_t>(n_live_upper, 64u * CHIP_BLOCK), st, B, bounce, 1); \
+    if (p.cache) launch_extend_t<FEAT, true, true>(s, P, p, n_live_upper, st, B, bounce, 0);                 \
+    else launch_extend_t<FEAT, false, true>(s, P, p, n_live_upper, st, B, bounce, 0);                        \
+    launch_extend_t<FEAT, false, false>(s, P, lit, std::min<uint32_t>(n_live_upper, 64u * CHIP_BLOCK), st, B, bounce, 1); \
   }
   switch (feat) {
     case 0: CHIP_EXT(0); break;
@@ -277,10 +301,13 @@ static void launch_shade(const DScene& S, const PathPool& P, const BatchDesc& B,
 }
 
 // Adds the rectangle's radiance sums for the planned strata into d_sum (device, rw*rh*3 floats).
+// The strata are cut into batches of as many paths as a pool holds.  With more than one batch, two
+// batches are in flight at a time, each in its own pool on its own stream; their kernels are enqueued
+// bounce by bounce in turn, so the device overlaps the traversal of one batch with the shading of the
+// other.  Batches add their samples to d_sum in batch order (chained events), which keeps the f32 sums
+// independent of how the device interleaved them.
 static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPlan& pl, float* d_sum, hipStream_t stream, chip_stats* stats) {
   HIP_TRY(hipSetDevice(s->device));
-  if (ensure_pool(s, (size_t)pl.rw * pl.rh * std::max<uint32_t>(pl.s_count, 1))) return -1;
-  const PathPool& P = s->pool;
   const DScene& S = s->dscene;
   const DCamera& cam = s->host.cam;
   const bool time_kernels = (o->flags & CHIP_RENDER_TIME_KERNELS) != 0;
@@ -291,30 +318,34 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
   // spheres with solid colours and no light sampling: the lean shade kernels
   bool lean = feat == 0 && !s->flat.has_lights;
   for (const DTexture& t : s->host.textures) lean = lean && t.kind == TK_SOLID;
-  hipEvent_t ev0, ev1;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
-  std::vector<hipEvent_t> kev;  // (begin, end) pairs: even index = trace launch, odd = shade group
-  std::vector<int> kev_kind;
-  auto new_event = [&]() {
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
-    kev.push_back(e);
-    return e;
+
+  // pools: two when the render is large enough to be worth splitting
+  const size_t want_total = (size_t)pl.rw * pl.rh * std::max<uint32_t>(pl.s_count, 1);
+  const char* e_streams = getenv("CHIP_STREAMS");
+  const bool two = want_total >= ((size_t)1 << 24) && pl.s_count >= 2 && !(e_streams && *e_streams == '1');
+  const size_t max_each = two ? pool_capacity_max() / 2 : pool_capacity_max();
+  const size_t want_each = two ? (size_t)pl.rw * pl.rh * ((pl.s_count + 1) / 2) : want_total;
+  const int n_lanes = two ? 2 : 1;
+  for (int k = 0; k < n_lanes; k++)
+    if (ensure_pool(s, k, want_each, max_each)) return -1;
+  const size_t cap = two ? std::min<size_t>(s->pools[0].P.cap, s->pools[1].P.cap) : s->pools[0].P.cap;
+  if (pl.rw > cap) return fail("render rectangle is wider than the path pool");
+
+  // batches: bands of rows (only when one stratum of the rectangle exceeds a pool) x groups of strata
+  struct Batch {
+    BatchDesc B;
+    uint32_t by;
   };
-  HIP_TRY(hipMemsetAsync(P.errflag, 0, 4 * sizeof(uint32_t), stream));
-  HIP_TRY(hipMemsetAsync(P.stats, 0, 4 * sizeof(unsigned long long), stream));
-  HIP_TRY(hipEventRecord(ev0, stream));
-  uint64_t n_paths_total = 0, n_trace_launches = 0, n_batches = 0;
-  if (pl.rw > P.cap) return fail("render rectangle is wider than the path pool");
-  uint32_t band_rows = std::min<uint32_t>(pl.rh, P.cap / pl.rw);
+  std::vector<Batch> batches;
+  const uint32_t band_rows = std::min<uint32_t>(pl.rh, (uint32_t)(cap / pl.rw));
   for (uint32_t by = 0; by < pl.rh; by += band_rows) {
-    uint32_t bh = std::min(band_rows, pl.rh - by);
-    uint32_t npix = pl.rw * bh;
-    uint32_t spb = o->strata_per_batch ? o->strata_per_batch : std::max<uint32_t>(1, P.cap / npix);
-    spb = std::min<uint32_t>(spb, std::max<uint32_t>(1, P.cap / npix));
+    const uint32_t bh = std::min(band_rows, pl.rh - by);
+    const uint32_t npix = pl.rw * bh;
+    uint32_t spb = std::max<uint32_t>(1, (uint32_t)(cap / npix));
+    if (o->strata_per_batch) spb = std::min(spb, o->strata_per_batch);
     for (uint32_t sb0 = 0; sb0 < pl.s_count; sb0 += spb) {
-      BatchDesc B;
+      Batch bt;
+      BatchDesc& B = bt.B;
       B.rect_x0 = pl.xmin; B.rect_y0 = pl.ymin + by; B.rect_w = pl.rw; B.rect_h = bh;
       B.npix = npix;
       B.n_strata = std::min(spb, pl.s_count - sb0);
@@ -324,60 +355,190 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       B.seed_lo = (uint32_t)o->seed;
       B.seed_hi = (uint32_t)(o->seed >> 32);
       B.reference_order = (o->flags & CHIP_RENDER_REFERENCE_ORDER) ? 1u : 0u;
-      n_paths_total += B.n_paths;
-      n_batches++;
-      HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)s->counters_rows * CHIP_CTR_STRIDE * sizeof(uint32_t), stream));
-      hipLaunchKernelGGL(k_raygen, dim3(grid_for(B.n_paths)), dim3(CHIP_BLOCK), 0, stream, S, P, B);
-      // a path writes its sample when it ends; with max_depth 0 no path ever starts (camera.rs:259-261)
-      if (cam.max_depth == 0) HIP_TRY(hipMemsetAsync(P.sample, 0, (size_t)B.n_paths * sizeof(float4), stream));
-      uint32_t live_upper = B.n_paths;
-      for (uint32_t bounce = 0; bounce < cam.max_depth; bounce++) {
-        uint32_t grid = grid_for(live_upper);
-        if (time_kernels) (void)hipEventRecord(new_event(), stream);
-        launch_extend(s, feat, live_upper, stream, B, bounce);
-        if (time_kernels) (void)hipEventRecord(new_event(), stream);
-        n_trace_launches++;
-        {
-          hipLaunchKernelGGL(k_bin, dim3(grid), dim3(CHIP_BLOCK), 0, stream, S, P, bounce, (uint32_t)((feat & TF_MEDIA) != 0));
-          // only the material kinds the scene contains can have queue entries
-          if (mat_mask & (1u << MK_LAMBERTIAN)) launch_shade<MK_LAMBERTIAN>(S, P, B, bounce, grid, stream, exact_shading, lean);
-          if (mat_mask & (1u << MK_METAL)) launch_shade<MK_METAL>(S, P, B, bounce, grid, stream, exact_shading, lean);
-          if (mat_mask & (1u << MK_DIELECTRIC)) launch_shade<MK_DIELECTRIC>(S, P, B, bounce, grid, stream, exact_shading, lean);
-          if (mat_mask & (1u << MK_DIFFUSE_LIGHT)) launch_shade<MK_DIFFUSE_LIGHT>(S, P, B, bounce, grid, stream, exact_shading, lean);
-          if (mat_mask & (1u << MK_ISOTROPIC)) launch_shade<MK_ISOTROPIC>(S, P, B, bounce, grid, stream, exact_shading, lean);
-          if (mat_mask & (1u << MK_EMPTY)) launch_shade<MK_EMPTY>(S, P, B, bounce, grid, stream, exact_shading, lean);
-        }
-        if (time_kernels) (void)hipEventRecord(new_event(), stream);
-        // every few bounces learn how many paths are still alive (stops the loop early)
-        if (bounce + 1 < cam.max_depth && (bounce % 4) == 3) {
-          HIP_TRY(hipMemcpyAsync(s->h_pinned, P.counters + (size_t)(bounce + 1) * CHIP_CTR_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-          HIP_TRY(hipStreamSynchronize(stream));
-          live_upper = s->h_pinned[0];
-          if (live_upper == 0) break;
-        }
-      }
-      hipLaunchKernelGGL(k_accumulate, dim3(grid_for(npix)), dim3(CHIP_BLOCK), 0, stream, P, B, d_sum + (size_t)by * pl.rw * 3);
-      HIP_TRY(hipGetLastError());
+      bt.by = by;
+      batches.push_back(bt);
     }
   }
-  HIP_TRY(hipEventRecord(ev1, stream));
-  HIP_TRY(hipMemcpyAsync(s->h_pinned + 8, P.errflag, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipMemcpyAsync(s->h_pinned + 16, P.stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  HIP_TRY(hipGetLastError());
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-  double ms_trace = 0.0, ms_shade = 0.0;
-  for (size_t i = 0; i + 2 < kev.size(); i += 3) {  // (trace begin, trace end = shade begin, shade end) per bounce
-    float a = 0.f, b = 0.f;
-    (void)hipEventElapsedTime(&a, kev[i], kev[i + 1]);
-    (void)hipEventElapsedTime(&b, kev[i + 1], kev[i + 2]);
-    ms_trace += a;
-    ms_shade += b;
+
+  struct Lane {
+    chip_scene::PoolBufs* pb = nullptr;
+    hipStream_t st = nullptr;
+    bool active = false;
+    size_t batch = 0;
+    uint32_t bounce = 0, live_upper = 0;
+    // live-count readbacks in flight: the host runs ahead of the device and only learns a bounce's live
+    // count (which sizes later grids and ends the batch early) when the copy has landed
+    hipEvent_t ev_rb[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t rb_head = 0, rb_count = 0;
+    std::vector<hipEvent_t> kev;  // (trace begin, trace end = shade begin, shade end) per bounce
+  };
+  Lane lanes[2];
+  const bool forked = n_lanes == 2 && batches.size() >= 2;
+  const int n_active_lanes = forked ? 2 : 1;
+  hipEvent_t ev0, ev1, ev_fork = nullptr;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  std::vector<hipEvent_t> ev_acc(batches.size(), nullptr);  // batch i has added its samples to d_sum
+  HIP_TRY(hipMemsetAsync(s->p_err.p, 0, 4 * sizeof(uint32_t), stream));
+  HIP_TRY(hipMemsetAsync(s->p_stats.p, 0, 4 * sizeof(unsigned long long), stream));
+  HIP_TRY(hipEventRecord(ev0, stream));
+  if (forked) {
+    HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev_fork, stream));
   }
-  for (hipEvent_t e : kev) (void)hipEventDestroy(e);
+  for (int k = 0; k < n_active_lanes; k++) {
+    lanes[k].pb = &s->pools[k];
+    lanes[k].st = forked ? s->pools[k].stream : stream;
+    if (forked) HIP_TRY(hipStreamWaitEvent(lanes[k].st, ev_fork, 0));
+    for (int j = 0; j < 4; j++) HIP_TRY(hipEventCreateWithFlags(&lanes[k].ev_rb[j], hipEventDisableTiming));
+  }
+  uint64_t n_paths_total = 0, n_trace_launches = 0;
+  size_t next_batch = 0;
+
+  auto finish_batch = [&](Lane& L) -> int {
+    const Batch& bt = batches[L.batch];
+    if (L.batch > 0 && ev_acc[L.batch - 1]) HIP_TRY(hipStreamWaitEvent(L.st, ev_acc[L.batch - 1], 0));
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(bt.B.npix)), dim3(CHIP_BLOCK), 0, L.st, L.pb->P, bt.B, d_sum + (size_t)bt.by * pl.rw * 3);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventCreateWithFlags(&ev_acc[L.batch], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev_acc[L.batch], L.st));
+    L.active = false;
+    return 0;
+  };
+  // Enqueues the lane's batch from its current bounce up to the next live-count readback (or its end).
+  auto advance = [&](Lane& L) -> int {
+    const Batch& bt = batches[L.batch];
+    const BatchDesc& B = bt.B;
+    const PathPool& P = L.pb->P;
+    auto new_event = [&]() {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      L.kev.push_back(e);
+      return e;
+    };
+    while (L.bounce < cam.max_depth) {
+      const uint32_t bounce = L.bounce;
+      const uint32_t grid = grid_for(L.live_upper);
+      if (time_kernels) (void)hipEventRecord(new_event(), L.st);
+      launch_extend(s, P, feat, L.live_upper, L.st, B, bounce);
+      if (time_kernels) (void)hipEventRecord(new_event(), L.st);
+      n_trace_launches++;
+      hipLaunchKernelGGL(k_bin, dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, bounce, (uint32_t)((feat & TF_MEDIA) != 0));
+      // only the material kinds the scene contains can have queue entries
+      if (mat_mask & (1u << MK_LAMBERTIAN)) launch_shade<MK_LAMBERTIAN>(S, P, B, bounce, grid, L.st, exact_shading, lean);
+      if (mat_mask & (1u << MK_METAL)) launch_shade<MK_METAL>(S, P, B, bounce, grid, L.st, exact_shading, lean);
+      if (mat_mask & (1u << MK_DIELECTRIC)) launch_shade<MK_DIELECTRIC>(S, P, B, bounce, grid, L.st, exact_shading, lean);
+      if (mat_mask & (1u << MK_DIFFUSE_LIGHT)) launch_shade<MK_DIFFUSE_LIGHT>(S, P, B, bounce, grid, L.st, exact_shading, lean);
+      if (mat_mask & (1u << MK_ISOTROPIC)) launch_shade<MK_ISOTROPIC>(S, P, B, bounce, grid, L.st, exact_shading, lean);
+      if (mat_mask & (1u << MK_EMPTY)) launch_shade<MK_EMPTY>(S, P, B, bounce, grid, L.st, exact_shading, lean);
+      if (time_kernels) (void)hipEventRecord(new_event(), L.st);
+      L.bounce++;
+      // every few bounces learn how many paths are still alive (sizes the grids, stops the loop early)
+      if (L.bounce < cam.max_depth && (bounce % 4) == 3) {
+        const uint32_t j = (L.rb_head + L.rb_count) % 4;
+        HIP_TRY(hipMemcpyAsync(L.pb->h_live + j, P.counters + (size_t)L.bounce * CHIP_CTR_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToHost, L.st));
+        HIP_TRY(hipEventRecord(L.ev_rb[j], L.st));
+        L.rb_count++;
+        return 0;
+      }
+    }
+    return finish_batch(L);
+  };
+  // Takes the readbacks that have landed (waiting for the oldest when `must` or when the ring is full).
+  auto poll_readbacks = [&](Lane& L, bool must) -> int {
+    while (L.rb_count) {
+      const uint32_t j = L.rb_head;
+      if (must || L.rb_count >= 3) {
+        HIP_TRY(hipEventSynchronize(L.ev_rb[j]));
+      } else {
+        hipError_t q = hipEventQuery(L.ev_rb[j]);
+        if (q == hipErrorNotReady) break;
+        HIP_TRY(q);
+      }
+      must = false;
+      L.live_upper = std::min(L.live_upper, L.pb->h_live[j]);
+      L.rb_head = (L.rb_head + 1) % 4;
+      L.rb_count--;
+    }
+    return 0;
+  };
+
+  int rc = 0;
+  for (;;) {
+    bool any = false;
+    for (int k = 0; k < n_active_lanes && rc == 0; k++) {
+      Lane& L = lanes[k];
+      if (!L.active) {
+        if (next_batch >= batches.size()) continue;
+        L.batch = next_batch++;
+        L.active = true;
+        L.bounce = 0;
+        const Batch& bt = batches[L.batch];
+        const PathPool& P = L.pb->P;
+        n_paths_total += bt.B.n_paths;
+        rc = hipMemsetAsync(P.counters, 0, (size_t)L.pb->counters_rows * CHIP_CTR_STRIDE * sizeof(uint32_t), L.st) == hipSuccess ? 0 : fail("hipMemsetAsync failed");
+        if (rc) break;
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(bt.B.n_paths)), dim3(CHIP_BLOCK), 0, L.st, S, P, bt.B);
+        // a path writes its sample when it ends; with max_depth 0 no path ever starts (camera.rs:259-261)
+        if (cam.max_depth == 0) (void)hipMemsetAsync(P.sample, 0, (size_t)bt.B.n_paths * sizeof(float4), L.st);
+        L.live_upper = bt.B.n_paths;
+      }
+      any = true;
+      rc = poll_readbacks(L, false);
+      if (rc) break;
+      if (L.live_upper == 0) rc = finish_batch(L);
+      else rc = advance(L);
+      if (rc == 0 && !L.active) {  // the batch is fully enqueued: its readbacks are of no further use
+        L.rb_head = 0;
+        L.rb_count = 0;
+      }
+    }
+    if (rc || !any) break;
+  }
+  if (rc == 0 && forked) {
+    for (int k = 0; k < n_active_lanes; k++) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(e, lanes[k].st));
+      HIP_TRY(hipStreamWaitEvent(stream, e, 0));
+      ev_acc.push_back(e);
+    }
+  }
+  if (rc == 0) {
+    HIP_TRY(hipEventRecord(ev1, stream));
+    HIP_TRY(hipMemcpyAsync(s->h_pinned + 8, s->p_err.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(s->h_pinned + 16, s->p_stats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipGetLastError());
+  } else {
+    (void)hipDeviceSynchronize();
+  }
+  float ms = 0.f;
+  double ms_trace = 0.0, ms_shade = 0.0;
+  if (rc == 0) {
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    for (int k = 0; k < n_active_lanes; k++) {
+      const std::vector<hipEvent_t>& kev = lanes[k].kev;
+      for (size_t i = 0; i + 2 < kev.size(); i += 3) {
+        float a = 0.f, b = 0.f;
+        (void)hipEventElapsedTime(&a, kev[i], kev[i + 1]);
+        (void)hipEventElapsedTime(&b, kev[i + 1], kev[i + 2]);
+        ms_trace += a;
+        ms_shade += b;
+      }
+    }
+  }
+  for (int k = 0; k < n_active_lanes; k++) {
+    for (hipEvent_t e : lanes[k].kev) (void)hipEventDestroy(e);
+    for (int j = 0; j < 4; j++)
+      if (lanes[k].ev_rb[j]) (void)hipEventDestroy(lanes[k].ev_rb[j]);
+  }
+  for (hipEvent_t e : ev_acc)
+    if (e) (void)hipEventDestroy(e);
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
   (void)hipEventDestroy(ev0);
   (void)hipEventDestroy(ev1);
+  if (rc) return rc;
   if (s->h_pinned[8] & 1u) return fail("traversal stack overflow (scene nesting deeper than the device stack)");
   if (stats) {
     const unsigned long long* st = (const unsigned long long*)(s->h_pinned + 16);
@@ -386,11 +547,11 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
     stats->bvh_visits = st[1];
     stats->prim_tests = st[2];
     stats->ms_total = ms;
-    stats->ms_trace = ms_trace;
+    stats->ms_trace = ms_trace;  // summed over both streams when two batches overlap
     stats->ms_shade = ms_shade;
     stats->ms_other = 0.0;
     stats->trace_launches = n_trace_launches;
-    stats->batches = n_batches;
+    stats->batches = batches.size();
   }
   return 0;
 }
@@ -787,7 +948,7 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
   if (n > 0xFFFFFFFFull) return fail("too many rays");
   static_assert(sizeof(chip_hit) == sizeof(DHitOut), "hit layout");
   HIP_TRY(hipSetDevice(s->device));
-  if (ensure_pool(s, 0)) return -1;
+  if (ensure_pool(s, 0, 0, 4096)) return -1;
   DevBuf<double> d_o, d_d, d_t;
   DevBuf<DHitOut> d_out;
   int rc = 0;
@@ -802,9 +963,9 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
       if ((e = d_t.alloc(n)) != hipSuccess) break;
       if ((e = hipMemcpy(d_t.p, tm, n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
     }
-    if ((e = hipMemset(s->pool.errflag, 0, 4 * sizeof(uint32_t))) != hipSuccess) break;
+    if ((e = hipMemset(s->p_err.p, 0, 4 * sizeof(uint32_t))) != hipSuccess) break;
 #define CHIP_TRACE(FEAT)                                                                                                         \
-  hipLaunchKernelGGL(k_trace_rays<FEAT>, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, s->dscene, s->pool, (uint32_t)seed, \
+  hipLaunchKernelGGL(k_trace_rays<FEAT>, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, s->dscene, s->pools[0].P, (uint32_t)seed, \
                      (uint32_t)(seed >> 32), (uint32_t)n, d_o.p, d_d.p, tm ? d_t.p : nullptr, d_out.p)
     switch (scene_features(s->flat)) {
       case 0: CHIP_TRACE(0); break;
@@ -817,7 +978,7 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
     if ((e = hipDeviceSynchronize()) != hipSuccess) break;
     if ((e = hipMemcpy(out, d_out.p, n * sizeof(DHitOut), hipMemcpyDeviceToHost)) != hipSuccess) break;
     uint32_t err[4];
-    if ((e = hipMemcpy(err, s->pool.errflag, sizeof(err), hipMemcpyDeviceToHost)) != hipSuccess) break;
+    if ((e = hipMemcpy(err, s->p_err.p, sizeof(err), hipMemcpyDeviceToHost)) != hipSuccess) break;
     if (err[0] & 1u) rc = fail("traversal stack overflow (scene nesting deeper than the device stack)");
   } while (0);
   d_o.release(); d_d.release(); d_t.release(); d_out.release();

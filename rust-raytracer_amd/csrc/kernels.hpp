@@ -1066,7 +1066,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
   uint32_t* lds_stack = reinterpret_cast<uint32_t*>(g_lds) + 16u * (cd.n_bvh + cd.n_sph);
   uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
   const uint32_t n_live = lit_pass ? ctr[CHIP_CTR_LIT] : ctr[0];
-  if (n_live == 0) return;
+  if ((size_t)blockIdx.x * 64u >= n_live) return;  // the grid is sized from an upper bound: surplus blocks leave at once
   if (CACHE) {
     for (uint32_t i = threadIdx.x; i < cd.n_bvh; i += blockDim.x) {
       const uint4* p = ORD ? reinterpret_cast<const uint4*>(S.tnodes + i) : reinterpret_cast<const uint4*>(S.bvh + i);
