@@ -840,7 +840,13 @@ int chip_commit(chip_scene* s) {
       uv[t] = r ? 1 : 0;
       return r;
     };
-    for (DMaterial& m : s->host.materials) m.flags = (m.tex >= 0 && needs(m.tex, 0)) ? MF_NEEDS_UV : 0u;
+    for (DMaterial& m : s->host.materials) {
+      m.flags = (m.tex >= 0 && needs(m.tex, 0)) ? MF_NEEDS_UV : 0u;
+      // a solid-colour texture's value rides in the material record (read by the lean shade kernels)
+      if ((m.kind == MK_LAMBERTIAN || m.kind == MK_DIFFUSE_LIGHT || m.kind == MK_ISOTROPIC) && m.tex >= 0 && (size_t)m.tex < T.size() &&
+          T[m.tex].kind == TK_SOLID)
+        for (int c = 0; c < 3; c++) m.p[c] = T[m.tex].p[c];
+    }
   }
   HIP_TRY(s->d_materials.upload(s->host.materials));
   HIP_TRY(s->d_textures.upload(s->host.textures));

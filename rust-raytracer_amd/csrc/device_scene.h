@@ -24,6 +24,13 @@ enum : uint32_t {
 #define NREF_INDEX(r) ((r)&0x0FFFFFFFu)
 #define NREF_NONE NREF(NK_NONE, 0x0FFFFFFF)
 
+// The `mat` word of a primitive record: material index in bits 0..20, that material's kind (MK_*) in
+// bits 21..23, so the traversal can tag a hit with its material kind without touching the material table.
+#define MATK_PACK(id, kind) ((uint32_t)(id) | ((uint32_t)(kind) << 21))
+#define MATK_ID(x) ((x)&0x1FFFFFu)
+#define MATK_KIND(x) (((x) >> 21) & 7u)
+#define MATK_MAX_MATERIALS (1u << 21)
+
 // One BVH node: its own box (tested on entry, as bounding_volume_hierarchy.rs:59 does)
 // and its two children in reference order (left is always visited first).
 struct alignas(64) DBvhNode {
@@ -47,7 +54,7 @@ struct alignas(16) DSphere {
   double c[3];   // center at time 0
   double dc[3];  // center motion per unit time
   double r;
-  uint32_t mat;
+  uint32_t mat;  // MATK_PACK
   nref_t xform;  // innermost Translate/Rotate ancestor, or NREF_NONE
   int32_t leaf_id;
   uint32_t seq;  // position of this primitive in the reference's depth-first visiting order

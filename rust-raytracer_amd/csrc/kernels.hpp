@@ -40,8 +40,10 @@ struct alignas(64) PathRay {  // what traversal reads and shading rewrites
 struct alignas(16) PathHit {  // what traversal writes: closest hit of the current segment
   double t;
   uint32_t node;  // node reference, NREF_NONE = miss
-  uint32_t draw;  // uniforms consumed during traversal (media free-flight samples)
+  uint32_t info;  // bits 0..23: the hit primitive's mat word (material index + kind); bits 24..31: uniforms
+                  // consumed during traversal (media free-flight samples)
 };
+#define PATHHIT_DRAW(info) ((info) >> 24)
 struct alignas(16) PathMap {  // x -> clamp(a + b x, lo, hi), the composed radiance map of the path so far
   float a[3], b[3], lo[3], hi[3];
 };
@@ -188,6 +190,7 @@ struct TravRay {
   // distances too large; capf is the current closest hit rounded up.
   float m_lo[3], m_hi[3], c_lo[3], c_hi[3];
   float capf;
+  uint32_t best_mat;  // mat word of the closest primitive so far
 };
 // The traversal kernel's dynamic LDS: [scene cache records][per-lane stacks].  Declared at file scope so
 // that device functions index it directly and the compiler emits ds_read / ds_write (a pointer to it
@@ -274,6 +277,7 @@ struct BvhRec {
 };
 struct SphereRec {
   double c[3], dc[3], r;
+  uint32_t mat;
 };
 __device__ inline double u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 template <bool CACHE>
@@ -305,6 +309,7 @@ __device__ inline void load_sphere(const DScene& S, const NodeCache& C, uint32_t
   n.c[2] = u2d(b.x, b.y); n.dc[0] = u2d(b.z, b.w);
   n.dc[1] = u2d(c.x, c.y); n.dc[2] = u2d(c.z, c.w);
   n.r = u2d(d.x, d.y);
+  n.mat = d.z;
 }
 
 struct TNodeRec {
@@ -593,10 +598,11 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
     if (node == NREF_NONE) break;
     const uint32_t kind = NREF_KIND(node), idx = NREF_INDEX(node);
     // candidate hit at t: closer wins; ORD settles exact ties by the reference's visiting order
-#define CHIP_TAKE(ref, tval)                                                  \
+#define CHIP_TAKE(ref, tval, matw)                                            \
   if (!ORD || (tval) < best_t || tie_wins(S, (ref), best)) {                  \
     best_t = (tval);                                                          \
     best = (ref);                                                             \
+    r.best_mat = (matw);                                                      \
     if (ORD) r.capf = f32_above(best_t);                                      \
   }
     if (kind == NK_SPHERE) {
@@ -604,11 +610,11 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       cnt.prim++;
       SphereRec sp;
       load_sphere<CACHE>(S, C, idx, sp);
-      if (ORD ? sphere_hit_incl(sp, r, tmin, best_t, t) : sphere_hit(sp, r, tmin, best_t, t)) { CHIP_TAKE(node, t) }
+      if (ORD ? sphere_hit_incl(sp, r, tmin, best_t, t) : sphere_hit(sp, r, tmin, best_t, t)) { CHIP_TAKE(node, t, sp.mat) }
     } else if ((F & TF_QUADS) && kind == NK_QUAD) {
       double t, al, be;
       cnt.prim++;
-      if (quad_hit(S.quads[idx], r, tmin, best_t, t, al, be)) { CHIP_TAKE(node, t) }
+      if (quad_hit(S.quads[idx], r, tmin, best_t, t, al, be)) { CHIP_TAKE(node, t, S.quads[idx].mat) }
     } else if ((F & TF_QUADS) && (kind == NK_GROUP || kind == NK_GROUP_CONT)) {
       // group.rs:44-54: children in order, each over the shrinking interval.  Primitive
       // children are tested inline; any other child is descended into, leaving a
@@ -624,12 +630,12 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
           double t;
           cnt.prim++;
           if (ORD ? sphere_hit_incl(S.spheres[NREF_INDEX(c)], r, tmin, best_t, t) : sphere_hit(S.spheres[NREF_INDEX(c)], r, tmin, best_t, t)) {
-            CHIP_TAKE(c, t)
+            CHIP_TAKE(c, t, S.spheres[NREF_INDEX(c)].mat)
           }
         } else if (ck == NK_QUAD) {
           double t, al, be;
           cnt.prim++;
-          if (quad_hit(S.quads[NREF_INDEX(c)], r, tmin, best_t, t, al, be)) { CHIP_TAKE(c, t) }
+          if (quad_hit(S.quads[NREF_INDEX(c)], r, tmin, best_t, t, al, be)) { CHIP_TAKE(c, t, S.quads[NREF_INDEX(c)].mat) }
         } else {
           if (pos + 1 < g.count) {
             st_push<ORD>(st, pos + 1);
@@ -667,6 +673,8 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
     } else if ((F & TF_MEDIA) && kind == NK_MEDIUM) {
       // constant_medium.rs:41-80
       const DMedium m = S.media[idx];
+      const uint32_t outer_mat = r.best_mat;  // the boundary queries below overwrite it
+      bool hit_medium = false;
       double t1 = INFINITY, t2 = INFINITY;
       nref_t b1 = NREF_NONE, b2 = NREF_NONE;
       traverse_boundary(S, m.boundary, r, -INFINITY, t1, b1, rng, st, cnt);
@@ -683,10 +691,12 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
             if (!(hit_distance > inside)) {
               best_t = t1 + hit_distance / ray_length;
               best = node;
+              hit_medium = true;
             }
           }
         }
       }
+      r.best_mat = hit_medium ? m.mat : outer_mat;
     }
     node = st_pop<ORD>(st, base, r.capf);
     if (YIELD && may_yield && __popcll(__ballot(1)) < CHIP_REFILL_THRESH) break;
@@ -749,7 +759,7 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
     if (want_uv) sphere_uv(outward, h.u, h.v);
     h.front = dot(d, outward) < 0.0;
     h.n = h.front ? outward : -outward;
-    h.mat = s.mat;
+    h.mat = MATK_ID(s.mat);
     h.leaf_id = s.leaf_id;
   } else if ((F & TF_QUADS) && kind == NK_QUAD) {
     const DQuad& q = S.quads[idx];
@@ -760,7 +770,7 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
     V3 n = ld3(q.n);
     h.front = dot(d, n) < 0.0;
     h.n = h.front ? n : -n;
-    h.mat = q.mat;
+    h.mat = MATK_ID(q.mat);
     h.leaf_id = q.leaf_id;
   } else if (F & TF_MEDIA) {
     const DMedium& m = S.media[idx];
@@ -768,7 +778,7 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
     h.u = 0.0;
     h.v = 0.0;
     h.front = true;
-    h.mat = m.mat;
+    h.mat = MATK_ID(m.mat);
     h.leaf_id = m.leaf_id;
   }
   if (F & TF_XFORM) {
@@ -1120,7 +1130,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
         PathHit ph;
         ph.t = best_t;
         ph.node = best;
-        ph.draw = (F & TF_MEDIA) ? rng.draw : 0u;
+        ph.info = (r.best_mat & 0xFFFFFFu) | ((F & TF_MEDIA) ? (rng.draw << 24) : 0u);
         *reinterpret_cast<uint4*>(P.hit + slot) = *reinterpret_cast<const uint4*>(&ph);
       }
       has = false;
@@ -1214,7 +1224,8 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_bin(DScene S, PathPool P, uint32
     const uint32_t tile_n = min(tile, n_live - tile0);
     for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
       const uint32_t slot = q_in[tile0 + k];
-      const nref_t best = P.hit[slot].node;
+      const uint2 hit_words = *reinterpret_cast<const uint2*>(&P.hit[slot].node);
+      const nref_t best = hit_words.x;
       uint32_t kind = MK_COUNT;
       if (best == NREF_NONE) {
         Affine f;
@@ -1222,7 +1233,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_bin(DScene S, PathPool P, uint32
         float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
         finish_path(P, slot, f, bg);
       } else {
-        kind = S.materials[node_material(S, best)].kind;
+        kind = MATK_KIND(hit_words.y);
       }
       if (kind < MK_COUNT) s_rank[k] = (uint16_t)atomicAdd(&s_cnt[kind], 1u);
       s_slot[k] = slot;
@@ -1253,7 +1264,7 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
   affine_load_at(P, slot, bounce, f);
   // HitRecord of the segment's closest hit (object/mod.rs:31-51), rebuilt from (ray, t, node)
   const nref_t leaf = ph.node;
-  const DMaterial& M = S.materials[LEAN ? S.spheres[NREF_INDEX(leaf)].mat : node_material(S, leaf)];
+  const DMaterial& M = S.materials[MATK_ID(ph.info)];
   const bool has_lights = !LEAN && S.has_lights;
   HitOut hrec;
   reconstruct<LEAN ? 0u : (TF_QUADS | TF_XFORM | TF_MEDIA), FAST>(S, leaf, ph.t, ro, rd, rtime, hrec, !LEAN && (M.flags & MF_NEEDS_UV) != 0);
@@ -1275,7 +1286,7 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
     uint32_t x_, y_, pixel, stratum;
     slot_to_path(B, S.cam, slot, x_, y_, pixel, stratum);
     Rng rng;
-    rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, ph.draw);
+    rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, PATHHIT_DRAW(ph.info));
     V3 ndir;
     bool terminal = false;
     float e[3] = {0.f, 0.f, 0.f}, w[3];
@@ -1304,7 +1315,7 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
       w[0] = 1.f; w[1] = 1.f; w[2] = 1.f;
     } else {
       // Lambertian (lambertian.rs:29-49) / Isotropic (isotropic.rs:29-44): PDF branch, camera.rs:278-305
-      V3 atten = LEAN ? ld3(S.textures[M.tex].p) : tex_value(S, M.tex, hrec.u, hrec.v, pt);  // solid_color.rs:14-17
+      V3 atten = LEAN ? ld3(M.p) : tex_value(S, M.tex, hrec.u, hrec.v, pt);  // solid_color.rs:14-17 (colour copied into the material)
       bool use_light = false;
       if (has_lights) use_light = rng.next() < 0.5;  // mixture.rs:26-32
       if (FAST) {

@@ -357,7 +357,7 @@ struct HostScene {
       std::memset(&s, 0, sizeof(s));
       for (int i = 0; i < 3; i++) { s.c[i] = n.a[i]; s.dc[i] = n.a[3 + i]; }
       s.r = n.a[6];
-      s.mat = (uint32_t)n.mat;
+      s.mat = MATK_PACK(n.mat, H.materials[n.mat].kind);
       s.xform = xform;
       s.leaf_id = leaf_id;
       s.seq = seq++;
@@ -370,7 +370,7 @@ struct HostScene {
       for (int i = 0; i < 3; i++) { q.q[i] = n.a[i]; q.u[i] = n.a[3 + i]; q.v[i] = n.a[6 + i]; q.n[i] = n.a[9 + i]; q.w[i] = n.a[12 + i]; }
       q.d = n.a[15];
       q.area = n.a[16];
-      q.mat = (uint32_t)n.mat;
+      q.mat = MATK_PACK(n.mat, H.materials[n.mat].kind);
       q.xform = xform;
       q.leaf_id = leaf_id;
       q.seq = seq++;
@@ -457,7 +457,7 @@ struct HostScene {
           DMedium& m = F.media[idx];
           m.neg_inv_density = n.a[0];
           m.boundary = b;
-          m.mat = (uint32_t)n.mat;
+          m.mat = MATK_PACK(n.mat, H.materials[n.mat].kind);
           m.xform = xform;
           m.leaf_id = n.id;
           return NREF(NK_MEDIUM, idx);
@@ -479,6 +479,7 @@ struct HostScene {
 
   void flatten(Flat& F) const {
     if (world < 0) throw std::runtime_error("scene has no world");
+    if (materials.size() >= MATK_MAX_MATERIALS) throw std::runtime_error("too many materials (2^21 at most)");
     if (!has_camera) throw std::runtime_error("scene has no camera");
     Flattener fl(*this, F);
     F.root = fl.emit(handle[world], NREF_NONE, false, -1);
