@@ -24,11 +24,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("rust-raytracer_amd")
 
-# Device table sizes that define the algorithmic bytes of one ray segment of the traversal kernel.
-BYTES_BVH_NODE = 64    # DBvhNode: own box (6 f64) + two child refs, one 64-B record per visit
-BYTES_SPHERE = 80      # DSphere: centre, motion, radius (7 f64) + material / transform / id words
+# Device record sizes that define the algorithmic bytes of one ray segment of the traversal kernel.
+BYTES_BVH_NODE = 64    # DTNode: f32 boxes of both children (2 x 6 f32) + two child refs, one 64-B record per visit
+BYTES_SPHERE = 64      # the part of DSphere a test reads: centre, motion, radius (7 f64) + material word
 BYTES_SEGMENT_STATE = 64 + 4 + 16  # PathRay record read, live-queue entry read, PathHit record write
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+# HBM bytes per launch of the traversal kernel on the default workload (1920x1080, 64-strata batches, depth 50),
+# from rocprofv3 PMC passes of this build (2 x FETCH_SIZE + WRITE_SIZE, in KB, summed over the launches of one
+# frame and divided by their number): profiles/r01/pmc_traffic_k_extend.json.  None for any other workload.
+PMC_TRAFFIC_DEFAULT_WORKLOAD = 690.8e6
 
 
 def cpu_baseline(width, depth, seed):
@@ -153,13 +157,15 @@ def main():
                 "render_seed": args.seed,
             },
             "roofline": {
-                "kernel": "k_extend<0, true> (BVH traversal + sphere tests, f64, LDS scene cache)",
+                "kernel": "k_extend<0, true, true> (ordered BVH traversal: f32 child-box culling, f64 sphere tests, LDS scene cache)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": None,
+                "traffic": PMC_TRAFFIC_DEFAULT_WORKLOAD if (world == 1 and args.width == 1920 and args.spp == 1024 and args.depth == 50) else None,
+                "note": "achieved = algorithmic bytes (every node / sphere record counted as an HBM fetch) / kernel time; the scene "
+                        "tables are LDS-resident, so HBM only carries the path records (traffic) and the kernel is VALU-bound",
                 "algorithmic_bytes_per_launch": alg_bytes / launches if launches else None,
                 "avg_launch_ms": ms_trace / launches if launches else None,
                 "launches": launches,
