@@ -80,13 +80,13 @@ struct chip_scene {
     DevBuf<PathHit> hit;
     DevBuf<PathMap> st;
     DevBuf<float4> sample;
-    DevBuf<uint32_t> qlive0, qlive1, qmat, qlit, counters, ovf;
+    DevBuf<uint32_t> qlive0, qlive1, qlit, counters, ovf;
     uint32_t counters_rows = 0;
     uint32_t* h_live = nullptr;  // pinned: live-count readback
     hipStream_t stream = nullptr;
     void release() {
       ray.release(); hit.release(); st.release(); sample.release();
-      qlive0.release(); qlive1.release(); qmat.release(); qlit.release(); counters.release(); ovf.release();
+      qlive0.release(); qlive1.release(); qlit.release(); counters.release(); ovf.release();
       if (h_live) (void)hipHostFree(h_live);
       h_live = nullptr;
       if (stream) (void)hipStreamDestroy(stream);
@@ -128,7 +128,7 @@ static const uint32_t kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread
 
 // Largest path pool a render may use.  Every bounce of a batch is one round of kernel launches, and the
 // late bounces of a batch carry few paths, so batches are made as large as the frame allows: the
-// default of 2^28 path slots (176 B each, 47 GB) leaves that tail at a few per cent of a 1080p frame.
+// default of 2^28 path slots (156 B each, 42 GB) leaves that tail at a few per cent of a 1080p frame.
 static size_t pool_capacity_max() {
   const char* e = getenv("CHIP_POOL_PATHS");
   if (e && *e) {
@@ -137,7 +137,7 @@ static size_t pool_capacity_max() {
   }
   return (size_t)1 << 28;
 }
-static const size_t kBytesPerPathSlot = sizeof(PathRay) + sizeof(PathHit) + sizeof(PathMap) + sizeof(float4) + sizeof(uint32_t) * (3 + MK_COUNT);
+static const size_t kBytesPerPathSlot = sizeof(PathRay) + sizeof(PathHit) + sizeof(PathMap) + sizeof(float4) + sizeof(uint32_t) * 3;
 
 // Makes pool `which` hold min(want_paths, max_paths, what fits in free device memory) path slots.
 static int ensure_pool(chip_scene* s, int which, size_t want_paths, size_t max_paths) {
@@ -163,14 +163,13 @@ static int ensure_pool(chip_scene* s, int which, size_t want_paths, size_t max_p
   }
   if (!pb.ready || pb.P.cap < cap) {
     pb.ray.release(); pb.hit.release(); pb.st.release(); pb.sample.release();
-    pb.qlive0.release(); pb.qlive1.release(); pb.qmat.release(); pb.qlit.release();
+    pb.qlive0.release(); pb.qlive1.release(); pb.qlit.release();
     HIP_TRY(pb.ray.alloc(cap));
     HIP_TRY(pb.hit.alloc(cap));
     HIP_TRY(pb.st.alloc(cap));
     HIP_TRY(pb.sample.alloc(cap));
     HIP_TRY(pb.qlive0.alloc(cap));
     HIP_TRY(pb.qlive1.alloc(cap));
-    HIP_TRY(pb.qmat.alloc((size_t)MK_COUNT * cap));
     HIP_TRY(pb.qlit.alloc(cap));
     pb.P.cap = (uint32_t)cap;
   }
@@ -180,7 +179,7 @@ static int ensure_pool(chip_scene* s, int which, size_t want_paths, size_t max_p
   }
   PathPool& P = pb.P;
   P.ray = pb.ray.p; P.hit = pb.hit.p; P.st = pb.st.p; P.sample = pb.sample.p;
-  P.q_live[0] = pb.qlive0.p; P.q_live[1] = pb.qlive1.p; P.q_mat = pb.qmat.p; P.q_lit = pb.qlit.p;
+  P.q_live[0] = pb.qlive0.p; P.q_live[1] = pb.qlive1.p; P.q_lit = pb.qlit.p;
   P.counters = pb.counters.p; P.errflag = s->p_err.p; P.stats = s->p_stats.p; P.ovf = pb.ovf.p;
   pb.ready = true;
   return 0;
@@ -289,17 +288,6 @@ static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat,
 #undef CHIP_EXT
 }
 
-template <uint32_t K>
-static void launch_shade(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, uint32_t grid, hipStream_t st, bool exact, bool lean) {
-  if (lean) {
-    if (exact) hipLaunchKernelGGL((k_shade<K, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
-    else hipLaunchKernelGGL((k_shade<K, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
-  } else {
-    if (exact) hipLaunchKernelGGL((k_shade<K, false, false>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
-    else hipLaunchKernelGGL((k_shade<K, true, false>), dim3(grid), dim3(CHIP_BLOCK), 0, st, S, P, B, bounce);
-  }
-}
-
 // Adds the rectangle's radiance sums for the planned strata into d_sum (device, rw*rh*3 floats).
 // The strata are cut into batches of as many paths as a pool holds.  With more than one batch, two
 // batches are in flight at a time, each in its own pool on its own stream; their kernels are enqueued
@@ -313,8 +301,6 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
   const bool time_kernels = (o->flags & CHIP_RENDER_TIME_KERNELS) != 0;
   const bool exact_shading = (o->flags & CHIP_RENDER_EXACT_SHADING) != 0;
   const uint32_t feat = scene_features(s->flat);
-  uint32_t mat_mask = 0;
-  for (const DMaterial& m : s->host.materials) mat_mask |= 1u << m.kind;
   // spheres with solid colours and no light sampling: the lean shade kernels
   bool lean = feat == 0 && !s->flat.has_lights;
   for (const DTexture& t : s->host.textures) lean = lean && t.kind == TK_SOLID;
@@ -423,14 +409,13 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       launch_extend(s, P, feat, L.live_upper, L.st, B, bounce);
       if (time_kernels) (void)hipEventRecord(new_event(), L.st);
       n_trace_launches++;
-      hipLaunchKernelGGL(k_bin, dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, bounce, (uint32_t)((feat & TF_MEDIA) != 0));
-      // only the material kinds the scene contains can have queue entries
-      if (mat_mask & (1u << MK_LAMBERTIAN)) launch_shade<MK_LAMBERTIAN>(S, P, B, bounce, grid, L.st, exact_shading, lean);
-      if (mat_mask & (1u << MK_METAL)) launch_shade<MK_METAL>(S, P, B, bounce, grid, L.st, exact_shading, lean);
-      if (mat_mask & (1u << MK_DIELECTRIC)) launch_shade<MK_DIELECTRIC>(S, P, B, bounce, grid, L.st, exact_shading, lean);
-      if (mat_mask & (1u << MK_DIFFUSE_LIGHT)) launch_shade<MK_DIFFUSE_LIGHT>(S, P, B, bounce, grid, L.st, exact_shading, lean);
-      if (mat_mask & (1u << MK_ISOTROPIC)) launch_shade<MK_ISOTROPIC>(S, P, B, bounce, grid, L.st, exact_shading, lean);
-      if (mat_mask & (1u << MK_EMPTY)) launch_shade<MK_EMPTY>(S, P, B, bounce, grid, L.st, exact_shading, lean);
+      if (lean) {
+        if (exact_shading) hipLaunchKernelGGL((k_shade_tiles<false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
+        else hipLaunchKernelGGL((k_shade_tiles<true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
+      } else {
+        if (exact_shading) hipLaunchKernelGGL((k_shade_tiles<false, false>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
+        else hipLaunchKernelGGL((k_shade_tiles<true, false>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
+      }
       if (time_kernels) (void)hipEventRecord(new_event(), L.st);
       L.bounce++;
       // every few bounces learn how many paths are still alive (sizes the grids, stops the loop early)

@@ -18,7 +18,6 @@
 #ifndef CHIP_REFILL_THRESH
 #define CHIP_REFILL_THRESH 1  // a traversing wave refills its idle lanes once fewer than this many are busy
 #endif
-#define CHIP_TILE 2048  // queue entries a block compacts locally before one global append
 #define CHIP_PI 3.14159265358979323846
 #define CHIP_BIG 1e30f
 // Per-bounce counter row: [0] live paths, [1 .. MK_COUNT] material queue lengths, then the cursors the
@@ -53,7 +52,6 @@ struct PathPool {
   PathMap* st;      // [cap]
   float4* sample;   // [cap] finished sample radiance (rgb, w unused)
   uint32_t* q_live[2];  // [cap] live path slots, ping-pong per bounce
-  uint32_t* q_mat;      // [MK_COUNT][cap] per-material-kind shade queues
   uint32_t* q_lit;      // [cap] paths whose current ray the literal traversal must trace
   uint32_t* counters;   // [max_depth+2][8]: [b][0] live entering bounce b, [b][1..6] material queue sizes, [b][7] live-queue cursor
   uint32_t* errflag;    // [4]: [0] traversal stack overflow
@@ -1192,63 +1190,6 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
   }
 }
 
-// Entries a block compacts per global append: up to CHIP_TILE, but small enough that a short queue
-// still spreads over the whole grid.
-__device__ inline uint32_t tile_size(uint32_t n, uint32_t blocks) {
-  uint32_t t = (n / blocks) & ~(uint32_t)(CHIP_BLOCK - 1);
-  return t < CHIP_BLOCK ? CHIP_BLOCK : (t > CHIP_TILE ? CHIP_TILE : t);
-}
-
-// Material of a hit node (sphere.rs:132, quad.rs:179, constant_medium.rs:78).
-__device__ inline uint32_t node_material(const DScene& S, nref_t leaf) {
-  uint32_t kind = NREF_KIND(leaf), idx = NREF_INDEX(leaf);
-  return kind == NK_SPHERE ? S.spheres[idx].mat : (kind == NK_QUAD ? S.quads[idx].mat : S.media[idx].mat);
-}
-
-// After traversal: misses return the background (camera.rs:264-266) and finish; hits are binned into
-// the shade queue of their material kind.  A block bins a tile of CHIP_TILE entries in LDS and reserves
-// its output ranges with one global atomic per material kind.
-__global__ void __launch_bounds__(CHIP_BLOCK) k_bin(DScene S, PathPool P, uint32_t bounce, uint32_t has_media) {
-  const uint32_t* q_in = P.q_live[bounce & 1];
-  uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
-  const uint32_t n_live = ctr[0];
-  const size_t cap = P.cap;
-  __shared__ uint32_t s_slot[CHIP_TILE];
-  __shared__ uint16_t s_rank[CHIP_TILE];
-  __shared__ uint8_t s_kind[CHIP_TILE];
-  __shared__ uint32_t s_cnt[MK_COUNT], s_base[MK_COUNT];
-  const uint32_t tile = tile_size(n_live, gridDim.x);
-  for (uint32_t tile0 = blockIdx.x * tile; tile0 < n_live; tile0 += gridDim.x * tile) {
-    if (threadIdx.x < MK_COUNT) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t tile_n = min(tile, n_live - tile0);
-    for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
-      const uint32_t slot = q_in[tile0 + k];
-      const uint2 hit_words = *reinterpret_cast<const uint2*>(&P.hit[slot].node);
-      const nref_t best = hit_words.x;
-      uint32_t kind = MK_COUNT;
-      if (best == NREF_NONE) {
-        Affine f;
-        affine_load_at(P, slot, bounce, f);
-        float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
-        finish_path(P, slot, f, bg);
-      } else {
-        kind = MATK_KIND(hit_words.y);
-      }
-      if (kind < MK_COUNT) s_rank[k] = (uint16_t)atomicAdd(&s_cnt[kind], 1u);
-      s_slot[k] = slot;
-      s_kind[k] = (uint8_t)kind;
-    }
-    __syncthreads();
-    if (threadIdx.x < MK_COUNT) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&ctr[1 + threadIdx.x], s_cnt[threadIdx.x]) : 0u;
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
-      const uint32_t kind = s_kind[k];
-      if (kind < MK_COUNT) P.q_mat[(size_t)kind * cap + s_base[kind] + s_rank[k]] = s_slot[k];
-    }
-    __syncthreads();
-  }
-}
 
 // One hit of one path: Material::emitted / scatter / scattering_pdf of material kind KIND plus the PDF
 // branch of camera.rs:278-305.  The segment's ray (ro, rd, rtime) and closest hit (ph) come from the
@@ -1399,42 +1340,84 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
   return cont;
 }
 
-// Material-binned shade: the hits of one material kind, taken from that kind's queue.
-template <uint32_t KIND, bool FAST, bool LEAN>
-__global__ void __launch_bounds__(CHIP_BLOCK) k_shade(DScene S, PathPool P, BatchDesc B, uint32_t bounce) {
+// Material-binned shading of one bounce.  A block takes a tile of the live queue, bins the tile's entries by
+// the material kind of their hit in LDS (a counting sort, misses last), and shades the tile kind after kind,
+// so a wave runs one material's code except where two kinds meet.  Misses take the background
+// (camera.rs:264-266); surviving paths are compacted in LDS and appended to the next bounce's live queue
+// with one global atomic per tile.  Binning per tile instead of through global per-material queues saves
+// a pass over the hit records and the queue traffic.
+#define CHIP_SHADE_TILE 1024
+template <bool FAST, bool LEAN>
+__global__ void __launch_bounds__(CHIP_BLOCK) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce) {
+  const uint32_t* q_in = P.q_live[bounce & 1];
+  uint32_t* q_out = P.q_live[(bounce + 1) & 1];
   uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
   uint32_t* ctr_next = P.counters + (size_t)(bounce + 1) * CHIP_CTR_STRIDE;
-  const uint32_t n = ctr[1 + KIND];
-  const uint32_t* q = P.q_mat + (size_t)KIND * P.cap;
-  uint32_t* q_out = P.q_live[(bounce + 1) & 1];
+  const uint32_t n_live = ctr[0];
   const bool last_bounce = bounce + 1 >= S.cam.max_depth;
-  // A block takes tiles of CHIP_TILE queue entries; surviving paths are compacted in LDS and appended
-  // to the next bounce's live queue with one global atomic per tile.
-  __shared__ uint32_t s_pend[CHIP_TILE];
-  __shared__ uint32_t s_cnt, s_base;
-  const uint32_t tile = tile_size(n, gridDim.x);
-  for (uint32_t tile0 = blockIdx.x * tile; tile0 < n; tile0 += gridDim.x * tile) {
-    if (threadIdx.x == 0) s_cnt = 0;
+  constexpr uint32_t NB = MK_COUNT + 1;        // material kinds + misses
+  __shared__ uint32_t s_a[CHIP_SHADE_TILE];    // queue order while sorting, then the tile's surviving paths
+  __shared__ uint32_t s_sorted[CHIP_SHADE_TILE];
+  __shared__ uint16_t s_rank[CHIP_SHADE_TILE];
+  __shared__ uint8_t s_kind[CHIP_SHADE_TILE];
+  __shared__ uint32_t s_cnt[NB], s_off[NB + 1], s_live, s_base;
+  // entries per tile: up to CHIP_SHADE_TILE, but small enough that a short queue still spreads over the grid
+  uint32_t tile = (n_live / gridDim.x) & ~(uint32_t)(CHIP_BLOCK - 1);
+  tile = tile < CHIP_BLOCK ? CHIP_BLOCK : (tile > CHIP_SHADE_TILE ? CHIP_SHADE_TILE : tile);
+  for (uint32_t tile0 = blockIdx.x * tile; tile0 < n_live; tile0 += gridDim.x * tile) {
+    if (threadIdx.x < NB) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_live = 0;
     __syncthreads();
-    const uint32_t tile_end = min(tile0 + tile, n);
-    for (uint32_t i = tile0 + threadIdx.x; i < tile_end; i += CHIP_BLOCK) {
-      const uint32_t slot = q[i];
-      PathHit ph;
-      *reinterpret_cast<uint4*>(&ph) = *reinterpret_cast<const uint4*>(P.hit + slot);
-      V3 ro, rd;
-      double rtime;
-      ray_load(P, slot, ro, rd, rtime);
-      const bool cont = shade_hit<KIND, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime);
-      if (KIND != MK_DIFFUSE_LIGHT && KIND != MK_EMPTY) {
-        if (cont) s_pend[atomicAdd(&s_cnt, 1u)] = slot;
+    const uint32_t tile_n = min(tile, n_live - tile0);
+    for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
+      const uint32_t slot = q_in[tile0 + k];
+      const uint2 hw = *reinterpret_cast<const uint2*>(&P.hit[slot].node);
+      const uint32_t kind = hw.x == NREF_NONE ? MK_COUNT : MATK_KIND(hw.y);
+      s_a[k] = slot;
+      s_kind[k] = (uint8_t)kind;
+      s_rank[k] = (uint16_t)atomicAdd(&s_cnt[kind], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t acc = 0;
+      for (uint32_t b = 0; b < NB; b++) { s_off[b] = acc; acc += s_cnt[b]; }
+      s_off[NB] = acc;
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) s_sorted[s_off[s_kind[k]] + s_rank[k]] = s_a[k];
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
+      const uint32_t slot = s_sorted[k];
+      uint32_t kind = 0;
+#pragma unroll
+      for (uint32_t b = 1; b < NB; b++) kind += (k >= s_off[b]) ? 1u : 0u;
+      bool cont = false;
+      if (kind == MK_COUNT) {  // camera.rs:264-266
+        Affine f;
+        affine_load_at(P, slot, bounce, f);
+        float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
+        finish_path(P, slot, f, bg);
+      } else {
+        PathHit ph;
+        *reinterpret_cast<uint4*>(&ph) = *reinterpret_cast<const uint4*>(P.hit + slot);
+        V3 ro, rd;
+        double rtime;
+        ray_load(P, slot, ro, rd, rtime);
+        switch (kind) {
+          case MK_LAMBERTIAN: cont = shade_hit<MK_LAMBERTIAN, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
+          case MK_METAL: cont = shade_hit<MK_METAL, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
+          case MK_DIELECTRIC: cont = shade_hit<MK_DIELECTRIC, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
+          case MK_DIFFUSE_LIGHT: cont = shade_hit<MK_DIFFUSE_LIGHT, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
+          case MK_ISOTROPIC: cont = shade_hit<MK_ISOTROPIC, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
+          default: cont = shade_hit<MK_EMPTY, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
+        }
       }
+      if (cont) s_a[atomicAdd(&s_live, 1u)] = slot;
     }
-    if (KIND != MK_DIFFUSE_LIGHT && KIND != MK_EMPTY) {
-      __syncthreads();
-      if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&ctr_next[0], s_cnt) : 0u;
-      __syncthreads();
-      for (uint32_t k = threadIdx.x; k < s_cnt; k += CHIP_BLOCK) q_out[s_base + k] = s_pend[k];
-    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_live ? atomicAdd(&ctr_next[0], s_live) : 0u;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < s_live; k += CHIP_BLOCK) q_out[s_base + k] = s_a[k];
     __syncthreads();
   }
 }
