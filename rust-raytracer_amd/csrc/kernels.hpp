@@ -16,7 +16,7 @@
 #define CHIP_STACK_LDS 16  // per-lane short stack entries kept in LDS
 #define CHIP_STACK_OVF 48  // further entries spill to a per-thread global slab
 #ifndef CHIP_REFILL_THRESH
-#define CHIP_REFILL_THRESH 1  // a traversing wave refills its idle lanes once fewer than this many are busy
+#define CHIP_REFILL_THRESH 48  // a traversing wave refills its idle lanes once fewer than this many are busy
 #endif
 #define CHIP_PI 3.14159265358979323846
 #define CHIP_BIG 1e30f
@@ -951,12 +951,14 @@ __device__ inline void affine_load(const PathPool& P, uint32_t slot, Affine& f) 
 }
 // The map of a path that has not bounced yet is the identity and is not stored.
 __device__ inline void affine_load_at(const PathPool& P, uint32_t slot, uint32_t bounce, Affine& f) {
-  if (bounce == 0) {
-#pragma unroll
-    for (int c = 0; c < 3; c++) { f.a[c] = 0.f; f.b[c] = 1.f; f.lo[c] = -CHIP_BIG; f.hi[c] = CHIP_BIG; }
-  } else {
-    affine_load(P, slot, f);
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 1.f), v1 = make_float4(1.f, 1.f, -CHIP_BIG, -CHIP_BIG), v2 = make_float4(-CHIP_BIG, CHIP_BIG, CHIP_BIG, CHIP_BIG);
+  if (bounce != 0) {
+    const float4* p = reinterpret_cast<const float4*>(P.st + slot);
+    v0 = p[0]; v1 = p[1]; v2 = p[2];
   }
+  f.a[0] = v0.x; f.a[1] = v0.y; f.a[2] = v0.z; f.b[0] = v0.w;
+  f.b[1] = v1.x; f.b[2] = v1.y; f.lo[0] = v1.z; f.lo[1] = v1.w;
+  f.lo[2] = v2.x; f.hi[0] = v2.y; f.hi[1] = v2.z; f.hi[2] = v2.w;
 }
 __device__ inline void affine_store(const PathPool& P, uint32_t slot, const Affine& f) {
   float4* p = reinterpret_cast<float4*>(P.st + slot);
@@ -1215,7 +1217,7 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
     // diffuse_light.rs:28-43: no scatter; emits on the front face only
     float x[3] = {0.f, 0.f, 0.f};
     if (front) {
-      V3 e = tex_value(S, M.tex, hrec.u, hrec.v, pt);
+      V3 e = LEAN ? ld3(M.p) : tex_value(S, M.tex, hrec.u, hrec.v, pt);
       x[0] = (float)e.x; x[1] = (float)e.y; x[2] = (float)e.z;
     }
     finish_path(P, slot, f, x);
@@ -1386,33 +1388,31 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade_tiles(DScene S, PathPool P
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) s_sorted[s_off[s_kind[k]] + s_rank[k]] = s_a[k];
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
+    // one loop per bin, so that each material's code is register-allocated on its own
+#define CHIP_SHADE_BIN(KIND)                                                                                     \
+  _Pragma("clang loop unroll(disable)")                                                                          \
+  for (uint32_t k = s_off[KIND] + threadIdx.x; k < s_off[KIND + 1]; k += CHIP_BLOCK) {                           \
+    const uint32_t slot = s_sorted[k];                                                                           \
+    PathHit ph;                                                                                                  \
+    *reinterpret_cast<uint4*>(&ph) = *reinterpret_cast<const uint4*>(P.hit + slot);                              \
+    V3 ro, rd;                                                                                                   \
+    double rtime;                                                                                                \
+    ray_load(P, slot, ro, rd, rtime);                                                                            \
+    if (shade_hit<KIND, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime)) s_a[atomicAdd(&s_live, 1u)] = slot; \
+  }
+    CHIP_SHADE_BIN(MK_LAMBERTIAN)
+    CHIP_SHADE_BIN(MK_METAL)
+    CHIP_SHADE_BIN(MK_DIELECTRIC)
+    CHIP_SHADE_BIN(MK_DIFFUSE_LIGHT)
+    CHIP_SHADE_BIN(MK_ISOTROPIC)
+    CHIP_SHADE_BIN(MK_EMPTY)
+#undef CHIP_SHADE_BIN
+    for (uint32_t k = s_off[MK_COUNT] + threadIdx.x; k < s_off[MK_COUNT + 1]; k += CHIP_BLOCK) {  // misses, camera.rs:264-266
       const uint32_t slot = s_sorted[k];
-      uint32_t kind = 0;
-#pragma unroll
-      for (uint32_t b = 1; b < NB; b++) kind += (k >= s_off[b]) ? 1u : 0u;
-      bool cont = false;
-      if (kind == MK_COUNT) {  // camera.rs:264-266
-        Affine f;
-        affine_load_at(P, slot, bounce, f);
-        float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
-        finish_path(P, slot, f, bg);
-      } else {
-        PathHit ph;
-        *reinterpret_cast<uint4*>(&ph) = *reinterpret_cast<const uint4*>(P.hit + slot);
-        V3 ro, rd;
-        double rtime;
-        ray_load(P, slot, ro, rd, rtime);
-        switch (kind) {
-          case MK_LAMBERTIAN: cont = shade_hit<MK_LAMBERTIAN, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
-          case MK_METAL: cont = shade_hit<MK_METAL, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
-          case MK_DIELECTRIC: cont = shade_hit<MK_DIELECTRIC, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
-          case MK_DIFFUSE_LIGHT: cont = shade_hit<MK_DIFFUSE_LIGHT, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
-          case MK_ISOTROPIC: cont = shade_hit<MK_ISOTROPIC, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
-          default: cont = shade_hit<MK_EMPTY, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime); break;
-        }
-      }
-      if (cont) s_a[atomicAdd(&s_live, 1u)] = slot;
+      Affine f;
+      affine_load_at(P, slot, bounce, f);
+      float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
+      finish_path(P, slot, f, bg);
     }
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_live ? atomicAdd(&ctr_next[0], s_live) : 0u;
