@@ -247,18 +247,24 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
   }
   return p;
 }
-template <uint32_t F, bool CACHE, bool ORD>
-static void launch_extend_t(const chip_scene* s, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
+template <uint32_t F, bool CACHE, bool ORD, bool B0>
+static void launch_extend_b(const chip_scene* s, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
                             uint32_t bounce, uint32_t lit_pass) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_extend<F, CACHE, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    (void)hipFuncSetAttribute((const void*)k_extend<F, CACHE, ORD, B0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     attr_set = true;
   }
   uint32_t blocks = (n_live_upper + p.block - 1) / p.block;
   uint32_t max_blocks = CACHE ? (uint32_t)s->n_cus : kMaxGridBlocksDef;
   blocks = std::max(1u, std::min(blocks, max_blocks));
-  hipLaunchKernelGGL((k_extend<F, CACHE, ORD>), dim3(blocks), dim3(p.block), p.lds_bytes, st, s->dscene, P, B, bounce, p.cd, lit_pass);
+  hipLaunchKernelGGL((k_extend<F, CACHE, ORD, B0>), dim3(blocks), dim3(p.block), p.lds_bytes, st, s->dscene, P, B, bounce, p.cd, lit_pass);
+}
+template <uint32_t F, bool CACHE, bool ORD>
+static void launch_extend_t(const chip_scene* s, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
+                            uint32_t bounce, uint32_t lit_pass) {
+  if (bounce == 0) launch_extend_b<F, CACHE, ORD, true>(s, P, p, n_live_upper, st, B, bounce, lit_pass);
+  else launch_extend_b<F, CACHE, ORD, false>(s, P, p, n_live_upper, st, B, bounce, lit_pass);
 }
 // One bounce of traversal.  ConstantMedium scenes and reference_order renders replay the reference's order for
 // every ray; everything else runs the ordered traversal followed by a (normally empty) literal pass over the
@@ -463,7 +469,7 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
         n_paths_total += bt.B.n_paths;
         rc = hipMemsetAsync(P.counters, 0, (size_t)L.pb->counters_rows * CHIP_CTR_STRIDE * sizeof(uint32_t), L.st) == hipSuccess ? 0 : fail("hipMemsetAsync failed");
         if (rc) break;
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(bt.B.n_paths)), dim3(CHIP_BLOCK), 0, L.st, S, P, bt.B);
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, L.st, P, bt.B);
         // a path writes its sample when it ends; with max_depth 0 no path ever starts (camera.rs:259-261)
         if (cam.max_depth == 0) (void)hipMemsetAsync(P.sample, 0, (size_t)bt.B.n_paths * sizeof(float4), L.st);
         L.live_upper = bt.B.n_paths;

@@ -1030,22 +1030,24 @@ __device__ inline void camera_ray(const DCamera& cam, Rng& rng, uint32_t x, uint
   time = rng.next();
 }
 
-// ------------------------------------------------------------------ kernels
-__global__ void __launch_bounds__(CHIP_BLOCK) k_raygen(DScene S, PathPool P, BatchDesc B) {
-  for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < B.n_paths; slot += gridDim.x * blockDim.x) {
-    uint32_t x, y, pixel, stratum;
-    slot_to_path(B, S.cam, slot, x, y, pixel, stratum);
-    Rng rng;
-    rng.init(B.seed_lo, B.seed_hi, pixel, stratum, CHIP_CAMERA_BOUNCE, 0);
-    V3 o, d;
-    double time;
-    camera_ray(S.cam, rng, x, y, stratum % S.cam.sqrt_spp, stratum / S.cam.sqrt_spp, o, d, time);
-    ray_store_od(P, slot, o, d);
-    reinterpret_cast<double2*>(P.ray + slot)[3] = make_double2(time, 0.0);
-    // the radiance map starts as the identity, which bounce 0 assumes without reading it; every path
-    // writes its sample exactly once when it ends
-    P.q_live[0][slot] = slot;
-  }
+// The camera ray of path `slot` of a batch (camera.rs:359-374).  Camera rays are never stored: the
+// traversal and the shading of bounce 0 both compute them from the path's Philox stream, which costs a
+// few hundred VALU operations against 192 bytes of HBM traffic per path.
+__device__ inline void path_camera_ray(const DScene& S, const BatchDesc& B, uint32_t slot, V3& o, V3& d, double& time) {
+  uint32_t x, y, pixel, stratum;
+  slot_to_path(B, S.cam, slot, x, y, pixel, stratum);
+  Rng rng;
+  rng.init(B.seed_lo, B.seed_hi, pixel, stratum, CHIP_CAMERA_BOUNCE, 0);
+  camera_ray(S.cam, rng, x, y, stratum % S.cam.sqrt_spp, stratum / S.cam.sqrt_spp, o, d, time);
+}
+// The ray of the path's current segment: the camera ray at bounce 0, afterwards what shading stored.
+__device__ inline void segment_ray(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, uint32_t slot, V3& o, V3& d, double& time) {
+  if (bounce == 0) path_camera_ray(S, B, slot, o, d, time);
+  else ray_load(P, slot, o, d, time);
+}
+
+// Starts a batch: every path is live at bounce 0 (their queue is the identity and is not stored either).
+__global__ void k_begin_batch(PathPool P, BatchDesc B) {
   if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[0] = B.n_paths;
 }
 
@@ -1065,11 +1067,17 @@ struct CacheDesc {
 };
 // Threads per block of the traversal kernel: with the LDS scene cache one block owns a whole CU's LDS.
 __host__ __device__ constexpr int extend_block(uint32_t F, bool CACHE) { return CACHE ? ((F & TF_MEDIA) ? 512 : 1024) : CHIP_BLOCK; }
+// Waves per SIMD the traversal kernel is register-allocated for.  The LDS-cached sphere-scene kernel asks for 6
+// (at most 80 VGPRs) although only 4 of its own waves fit beside its LDS: the registers it leaves free are
+// what lets two shade waves per SIMD of the other batch run next to it.
 __host__ __device__ constexpr int extend_min_waves(uint32_t F, bool CACHE) {
-  return CACHE ? 1 : ((F & TF_MEDIA) ? 1 : ((F & TF_XFORM) ? 2 : CHIP_EXTEND_WAVES));
+  return CACHE ? (F == 0 ? 6 : 1) : ((F & TF_MEDIA) ? 1 : ((F & TF_XFORM) ? 2 : CHIP_EXTEND_WAVES));
 }
-template <uint32_t F, bool CACHE, bool ORD>
-__global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CACHE)) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce, CacheDesc cd, uint32_t lit_pass) {
+// B0: the instantiation for bounce 0 (camera rays are computed, not loaded), kept apart so that the
+// camera code does not cost the other bounces registers.
+template <uint32_t F, bool CACHE, bool ORD, bool B0>
+__global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CACHE)) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg, CacheDesc cd, uint32_t lit_pass) {
+  const uint32_t bounce = B0 ? 0u : bounce_arg;
   static_assert(!(ORD && (F & TF_MEDIA)), "ConstantMedium scenes are traced in the reference's order");
   // LDS layout: [4 x n_bvh uint4][4 x n_sph uint4][stack_entries x blockDim u32 values][the same again: entry distances (ORD)]
   const NodeCache C{0u, 4u * cd.n_bvh, cd.n_bvh, cd.n_sph, cd.n_bvh, cd.n_sph};
@@ -1151,8 +1159,9 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
         const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
         const uint32_t avail = w_end - w_next;
         if (!has && rank < avail) {
-          slot = q_in[w_next + rank];
-          ray_load(P, slot, r.wo, r.wd, r.time);
+          slot = (B0 && !lit_pass) ? w_next + rank : q_in[w_next + rank];
+          if (B0) path_camera_ray(S, B, slot, r.wo, r.wd, r.time);
+          else ray_load(P, slot, r.wo, r.wd, r.time);
           if (ORD && has_zero_component(r.wd)) {
             P.q_lit[atomicAdd(&ctr[CHIP_CTR_LIT], 1u)] = slot;
           } else {
@@ -1334,7 +1343,8 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
         finish_path(P, slot, f, x);
       } else {
         affine_store(P, slot, f);
-        ray_store_od(P, slot, pt, ndir);  // the time of the path's rays never changes (camera.rs:287)
+        ray_store_od(P, slot, pt, ndir);  // the time of the path's rays never changes (camera.rs:287):
+        if (bounce == 0) reinterpret_cast<double2*>(P.ray + slot)[3] = make_double2(rtime, 0.0);  // stored once
         cont = true;
       }
     }
@@ -1372,7 +1382,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade_tiles(DScene S, PathPool P
     __syncthreads();
     const uint32_t tile_n = min(tile, n_live - tile0);
     for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
-      const uint32_t slot = q_in[tile0 + k];
+      const uint32_t slot = bounce == 0 ? tile0 + k : q_in[tile0 + k];
       const uint2 hw = *reinterpret_cast<const uint2*>(&P.hit[slot].node);
       const uint32_t kind = hw.x == NREF_NONE ? MK_COUNT : MATK_KIND(hw.y);
       s_a[k] = slot;
@@ -1397,7 +1407,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade_tiles(DScene S, PathPool P
     *reinterpret_cast<uint4*>(&ph) = *reinterpret_cast<const uint4*>(P.hit + slot);                              \
     V3 ro, rd;                                                                                                   \
     double rtime;                                                                                                \
-    ray_load(P, slot, ro, rd, rtime);                                                                            \
+    segment_ray(S, P, B, bounce, slot, ro, rd, rtime);                                                           \
     if (shade_hit<KIND, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime)) s_a[atomicAdd(&s_live, 1u)] = slot; \
   }
     CHIP_SHADE_BIN(MK_LAMBERTIAN)
