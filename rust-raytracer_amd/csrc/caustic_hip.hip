@@ -266,9 +266,9 @@ static void launch_extend_t(const chip_scene* s, const PathPool& P, const Extend
   if (bounce == 0) launch_extend_b<F, CACHE, ORD, true>(s, P, p, n_live_upper, st, B, bounce, lit_pass);
   else launch_extend_b<F, CACHE, ORD, false>(s, P, p, n_live_upper, st, B, bounce, lit_pass);
 }
-// One bounce of traversal.  ConstantMedium scenes and reference_order renders replay the reference's order for
-// every ray; everything else runs the ordered traversal followed by a (normally empty) literal pass over the
-// rays it handed back.
+// One bounce of traversal.  ConstantMedium scenes replay the reference's order for every ray; everything else
+// runs the ordered traversal followed by a literal pass over the rays it handed back (normally none; all of
+// them in a reference_order render).
 static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce) {
   if (feat & TF_MEDIA) {
     const ExtendPlan p = plan_extend(s, feat, false);
@@ -278,14 +278,10 @@ static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat,
   }
   const ExtendPlan lit = plan_extend(s, feat, true);
   const ExtendPlan p = plan_extend(s, feat, false);
-#define CHIP_EXT(FEAT)                                                                                    \
-  if (B.reference_order) {                                                                                \
-    launch_extend_t<FEAT, false, false>(s, P, lit, n_live_upper, st, B, bounce, 0);                          \
-  } else {                                                                                                \
-    if (p.cache) launch_extend_t<FEAT, true, true>(s, P, p, n_live_upper, st, B, bounce, 0);                 \
-    else launch_extend_t<FEAT, false, true>(s, P, p, n_live_upper, st, B, bounce, 0);                        \
-    launch_extend_t<FEAT, false, false>(s, P, lit, std::min<uint32_t>(n_live_upper, 64u * CHIP_BLOCK), st, B, bounce, 1); \
-  }
+#define CHIP_EXT(FEAT)                                                                                             \
+  if (p.cache) launch_extend_t<FEAT, true, true>(s, P, p, n_live_upper, st, B, bounce, 0);                         \
+  else launch_extend_t<FEAT, false, true>(s, P, p, n_live_upper, st, B, bounce, 0);                                \
+  launch_extend_t<FEAT, false, false>(s, P, lit, B.reference_order ? n_live_upper : std::min<uint32_t>(n_live_upper, 64u * CHIP_BLOCK), st, B, bounce, 1)
   switch (feat) {
     case 0: CHIP_EXT(0); break;
     case TF_QUADS: CHIP_EXT(TF_QUADS); break;
@@ -314,7 +310,9 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
   // pools: two when the render is large enough to be worth splitting
   const size_t want_total = (size_t)pl.rw * pl.rh * std::max<uint32_t>(pl.s_count, 1);
   const char* e_streams = getenv("CHIP_STREAMS");
-  const bool two = want_total >= ((size_t)1 << 24) && pl.s_count >= 2 && !(e_streams && *e_streams == '1');
+  size_t overlap_min = (size_t)1 << 24;  // renders smaller than this are not worth splitting
+  if (const char* e_min = getenv("CHIP_OVERLAP_MIN_PATHS")) overlap_min = (size_t)std::max<long long>(0, atoll(e_min));
+  const bool two = want_total >= overlap_min && pl.s_count >= 2 && !(e_streams && *e_streams == '1');
   const size_t max_each = two ? pool_capacity_max() / 2 : pool_capacity_max();
   const size_t want_each = two ? (size_t)pl.rw * pl.rh * ((pl.s_count + 1) / 2) : want_total;
   const int n_lanes = two ? 2 : 1;

@@ -1162,9 +1162,18 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
           slot = (B0 && !lit_pass) ? w_next + rank : q_in[w_next + rank];
           if (B0) path_camera_ray(S, B, slot, r.wo, r.wd, r.time);
           else ray_load(P, slot, r.wo, r.wd, r.time);
-          if (ORD && has_zero_component(r.wd)) {
-            P.q_lit[atomicAdd(&ctr[CHIP_CTR_LIT], 1u)] = slot;
-          } else {
+          const bool to_literal = ORD && (B.reference_order || has_zero_component(r.wd));
+          if (ORD) {  // the literal queue takes these rays (appended with one atomic per wave)
+            const unsigned long long ml = __ballot(to_literal);
+            if (ml) {
+              const uint32_t leader = (uint32_t)__ffsll((long long)ml) - 1u;
+              uint32_t lbase = 0;
+              if (lane == leader) lbase = atomicAdd(&ctr[CHIP_CTR_LIT], (uint32_t)__popcll(ml));
+              lbase = __shfl(lbase, leader);
+              if (to_literal) P.q_lit[lbase + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull))] = slot;
+            }
+          }
+          if (!to_literal) {
             r.o = r.wo; r.d = r.wd;
             ray_set_inv<ORD>(r);
             r.capf = INFINITY;

@@ -279,3 +279,43 @@ def test_ordered_traversal_equals_reference_order_render(pkg, gpu, name):
     b, _, sb = sg.render_frame(seed=3, flags=pkg.bindings.RENDER_REFERENCE_ORDER)
     assert sa["segments"] == sb["segments"]
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_overlapped_batches_equal_single_stream(pkg, gpu, monkeypatch):
+    """Many small batches run two at a time on two streams (the production path of a large frame) add up
+    to exactly the image of the same batches run one after the other."""
+    sg = pkg.scenes.build(gpu, "random_spheres", width=200, spp=64, depth=30)
+    monkeypatch.setenv("CHIP_STREAMS", "1")
+    a, _, sa = sg.render_frame(seed=9, strata_per_batch=5)
+    monkeypatch.delenv("CHIP_STREAMS")
+    monkeypatch.setenv("CHIP_OVERLAP_MIN_PATHS", "1000")
+    b, _, sb = sg.render_frame(seed=9, strata_per_batch=5)
+    assert sa["batches"] == sb["batches"] >= 12
+    assert sa["segments"] == sb["segments"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_zero_component_rays(pkg, gpu, oracle):
+    """Rays with an exactly zero direction component go through the literal traversal (their slab arithmetic
+    forms NaNs in the reference, aabb.rs:202-228); a mirror scene rendered with the same seed must also match.
+    The literal *queue* of the render path is exercised by the reference-order render test above."""
+    def build(be):
+        sc = be.new_scene()
+        mirror = sc.metal(0.9, 0.9, 0.9, 0.0)
+        red = sc.lambertian_color(0.8, 0.2, 0.2)
+        nodes = [sc.sphere((0, 0, -3), 1.0, red), sc.sphere((0, 0, -1005), 1000.0, mirror), sc.sphere((2.5, 0, -3), 1.0, mirror)]
+        sc.set_world(sc.bvh(nodes))
+        sc.set_camera(image_width=48, aspect_ratio=1.0, samples_per_pixel=16, max_depth=8, vertical_fov=40, look_from=(0, 0, 4), look_at=(0, 0, 0),
+                      background=(0.6, 0.7, 1.0))
+        sc.commit()
+        return sc
+    sg, so = build(gpu), build(oracle)
+    o = np.array([[0.0, 0.0, 4.0], [2.5, 0.0, 4.0], [0.0, 1.0, 4.0], [-1.0, 0.0, 4.0], [0.0, 0.0, -3.0], [0.0, 0.0, 4.0]])
+    d = np.array([[0.0, 0.0, -1.0], [0.0, 0.0, -2.0], [0.0, -0.25, -1.0], [0.25, 0.0, -1.0], [0.0, 1.0, 0.0], [0.0, 1.0, 0.0]])
+    info = compare_hits(sg.trace_rays(o, d, None, seed=1), so.trace_rays(o, d, None, seed=1))
+    assert info["n_hit"] >= 5
+    img_g, _, st_g = sg.render_frame(seed=4, flags=pkg.bindings.RENDER_EXACT_SHADING)
+    img_o, _, st_o = so.render_frame(seed=4, sum_dtype=np.float64)
+    assert st_g["segments"] == st_o["segments"]
+    diff = np.abs(img_g.astype(np.float64) - img_o)
+    assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
