@@ -102,7 +102,8 @@ enum {
 };
 enum { CHIP_MAT_LAMBERTIAN = 0, CHIP_MAT_METAL = 1, CHIP_MAT_DIELECTRIC = 2, CHIP_MAT_DIFFUSE_LIGHT = 3, CHIP_MAT_ISOTROPIC = 4, CHIP_MAT_EMPTY = 5 };
 /* node kinds reported by chip_dump_tree */
-enum { CHIP_NODE_BVH = 0, CHIP_NODE_SPHERE = 1, CHIP_NODE_QUAD = 2, CHIP_NODE_GROUP = 3, CHIP_NODE_TRANSLATE = 4, CHIP_NODE_ROTATE = 5, CHIP_NODE_MEDIUM = 6, CHIP_NODE_BOX = 7 };
+enum { CHIP_NODE_BVH = 0, CHIP_NODE_SPHERE = 1, CHIP_NODE_QUAD = 2, CHIP_NODE_GROUP = 3, CHIP_NODE_TRANSLATE = 4, CHIP_NODE_ROTATE = 5, CHIP_NODE_MEDIUM = 6, CHIP_NODE_BOX = 7, CHIP_NODE_DISC = 8,
+       CHIP_NODE_CONE = 9, CHIP_NODE_CONE_WALL = 10, CHIP_NODE_SCALE = 11 };
 
 const char* chip_last_error(void);
 /* Number of HIP devices visible; < 0 when the HIP runtime cannot be initialised. */
@@ -141,6 +142,10 @@ int chip_group(chip_scene* s, const int32_t* nodes, int n);                     
 int chip_bvh(chip_scene* s, const int32_t* nodes, int n);                                  /* bounding_volume_hierarchy.rs:16-46 */
 int chip_translate(chip_scene* s, int node, const double offset[3]);                       /* translate.rs:15-22 */
 int chip_rotate(chip_scene* s, int node, const double axis[3], double angle_degrees);      /* rotate.rs:19-79 */
+int chip_scale(chip_scene* s, int node, double sx, double sy, double sz);                   /* scale.rs:18-60 */
+int chip_disc(chip_scene* s, const double center[3], double radius, const double normal[3], int mat); /* disc.rs:24-54 */
+/* ConeFrustum::new: top disc and bottom disc (each only when its radius > 1e-4) and the side wall, as a Group. */
+int chip_cone_frustum(chip_scene* s, const double base[3], double height, double top_radius, double bottom_radius, int mat); /* cone.rs:19-75 */
 int chip_constant_medium_color(chip_scene* s, int boundary, double density, double r, double g, double b); /* constant_medium.rs:31-37 */
 int chip_constant_medium_tex(chip_scene* s, int boundary, double density, int tex);        /* constant_medium.rs:19-29 */
 

@@ -474,7 +474,7 @@ struct HitRecord {  // object/mod.rs:31-39
   }
 };
 
-enum NodeKind { K_BVH = 0, K_SPHERE = 1, K_QUAD = 2, K_GROUP = 3, K_TRANSLATE = 4, K_ROTATE = 5, K_MEDIUM = 6, K_BOX = 7 };
+enum NodeKind { K_BVH = 0, K_SPHERE = 1, K_QUAD = 2, K_GROUP = 3, K_TRANSLATE = 4, K_ROTATE = 5, K_MEDIUM = 6, K_BOX = 7, K_DISC = 8, K_CONE = 9, K_CONE_WALL = 10, K_SCALE = 11 };
 
 struct Node {  // object/mod.rs:54-68
   int id = -1;  // creation id; -1 for nodes made internally (BVH interior, box faces)
@@ -841,6 +841,176 @@ struct BoxPrimitive : Node {
   const AABB& bounding_box() const override { return group.bounding_box(); }
 };
 
+// ---------------------------------------------------------------- object/disc.rs
+struct Disc : Node {
+  Vec3 center;
+  double radius;
+  Vec3 normal;
+  std::shared_ptr<Material> material;
+  AABB bbox;
+  // disc.rs:24-54
+  Disc(const Vec3& c, double r, const Vec3& n, std::shared_ptr<Material> m) : center(c), radius(r), normal(n), material(std::move(m)) {
+    double radius_y = std::fabs(n.y) > 0.9 ? 0.0 : r;
+    double radius_x = std::fabs(n.x) > 0.9 ? 0.0 : r;
+    double radius_z = std::fabs(n.z) > 0.9 ? 0.0 : r;
+    double delta = 1e-4;
+    Vec3 ext(radius_x + std::fabs(n.x) * delta, radius_y + std::fabs(n.y) * delta, radius_z + std::fabs(n.z) * delta);
+    bbox = AABB::from_points(c - ext, c + ext);
+  }
+  int kind() const override { return K_DISC; }
+  // disc.rs:111-150 (+ get_uv disc.rs:57-66)
+  bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
+    ctx.n_prim_tests++;
+    double denominator = ray.direction.dot(normal);
+    if (std::fabs(denominator) < 1e-8) return false;
+    double t = (center - ray.origin).dot(normal) / denominator;
+    if (!ray_t.contains(t)) return false;
+    Vec3 pt = ray.at(t);
+    Vec3 v = pt - center;
+    if (v.length_squared() > radius * radius) return false;
+    Vec3 local_pt = pt - center;
+    rec.pt = pt;
+    rec.t = t;
+    rec.u = (local_pt.x / radius + 1.0) * 0.5;
+    rec.v = (local_pt.z / radius + 1.0) * 0.5;
+    rec.material = material.get();
+    rec.leaf_id = id;
+    rec.set_face_normal(ray, normal);
+    return true;
+  }
+  const AABB& bounding_box() const override { return bbox; }
+  // disc.rs:156-186
+  double pdf_value(RenderContext& ctx, const Vec3& origin, const Vec3& direction) const override {
+    HitRecord rec;
+    if (!hit(ctx, Ray(origin, direction), Interval(1e-4, kInf), rec)) return 0.0;
+    double dist_squared = rec.t * rec.t * direction.length_squared();
+    double cosine_abs = std::fabs(rec.normal.dot(-direction));
+    if (cosine_abs < 1e-8) return 0.0;
+    double area = kPi * radius * radius;
+    return dist_squared / (cosine_abs * area);
+  }
+  // disc.rs:188-193 with random_on_disc disc.rs:68-95
+  Vec3 random(RenderContext& ctx, const Vec3& origin) const override {
+    double r_sq = std::sqrt(ctx.random->rand());
+    double phi = 2.0 * kPi * ctx.random->rand();
+    double x = r_sq * std::cos(phi) * radius;
+    double y = r_sq * std::sin(phi) * radius;
+    ONB uvw(normal);
+    Vec3 random_local_pt = uvw.u * x + uvw.v * y;
+    Vec3 target = center + random_local_pt;
+    return target - origin;
+  }
+};
+
+// ---------------------------------------------------------------- object/cone.rs (the side wall)
+struct ConeFrustumWall : Node {
+  Vec3 base;
+  double height, r0, r1;  // r0 bottom radius, r1 top radius
+  std::shared_ptr<Material> material;
+  AABB bbox;
+  // cone.rs:116-147
+  ConeFrustumWall(const Vec3& b, double h, double r1_, double r0_, std::shared_ptr<Material> m)
+      : base(b), height(h), r0(r0_), r1(r1_), material(std::move(m)) {
+    double max_radius = std::fmax(r0, r1);
+    Vec3 min_p(b.x - max_radius, b.y, b.z - max_radius);
+    Vec3 max_p(b.x + max_radius, b.y + h, b.z + max_radius);
+    bbox = AABB::from_points(min_p, max_p);
+  }
+  int kind() const override { return K_CONE_WALL; }
+  // cone.rs:164-288
+  bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
+    ctx.n_prim_tests++;
+    double h = height;
+    double base_y = base.y;
+    Vec3 local_origin = ray.origin - base;
+    double ox = local_origin.x, oy = local_origin.y, oz = local_origin.z;
+    double dx = ray.direction.x, dy = ray.direction.y, dz = ray.direction.z;
+    double y_local = oy, dy_local = dy;
+    double dr = r1 - r0;
+    double k = dr / h;
+    double a = dx * dx + dz * dz - k * k * dy_local * dy_local;
+    double b = 2.0 * (ox * dx + oz * dz - k * k * y_local * dy_local - k * r0 * dy_local);
+    double c = ox * ox + oz * oz - (r0 * r0 + 2.0 * k * r0 * y_local + k * k * y_local * y_local);
+    if (std::fabs(a) < 1e-8) return false;
+    double discriminant = b * b - 4.0 * a * c;
+    if (discriminant < 0.0) return false;
+    double sqrt_discriminant = std::sqrt(discriminant);
+    double t = (-b - sqrt_discriminant) / (2.0 * a);
+    if (!ray_t.contains(t)) {
+      t = (-b + sqrt_discriminant) / (2.0 * a);
+      if (!ray_t.contains(t)) return false;
+    }
+    Vec3 pt = ray.at(t);
+    double hit_y = pt.y;
+    double y_min = base_y, y_max = base_y + h;
+    if (hit_y < y_min || hit_y > y_max) {
+      double t_other = (-b + sqrt_discriminant) / (2.0 * a);
+      if (t_other == t) return false;
+      if (!ray_t.contains(t_other)) return false;
+      Vec3 pt_other = ray.at(t_other);
+      if (pt_other.y < y_min || pt_other.y > y_max) return false;
+      t = t_other;
+    }
+    pt = ray.at(t);
+    double hit_y_local = pt.y - base_y;
+    double hit_radius = r0 + k * hit_y_local;
+    Vec3 pt_local = pt - base;
+    Vec3 outward_normal = Vec3(pt_local.x, k * hit_radius, pt_local.z).unit();
+    // get_uv(pt_local, 0.0, h), cone.rs:149-160
+    double phi = std::atan2(pt_local.z, pt_local.x);
+    double u = (phi + kPi) / (2.0 * kPi);
+    double v = rust_clamp((pt_local.y - 0.0) / h, 0.0, 1.0);
+    rec.pt = pt;
+    rec.t = t;
+    rec.u = u;
+    rec.v = v;
+    rec.material = material.get();
+    rec.leaf_id = id;
+    rec.set_face_normal(ray, outward_normal);
+    return true;
+  }
+  const AABB& bounding_box() const override { return bbox; }
+  // cone.rs:296-313: 1 / lateral area whatever the direction
+  double pdf_value(RenderContext&, const Vec3&, const Vec3&) const override {
+    double dr = r1 - r0;
+    double l = std::sqrt(height * height + dr * dr);
+    double area = kPi * (r0 + r1) * l;
+    return area > 1e-8 ? 1.0 / area : 0.0;
+  }
+  // cone.rs:315-347: returns a point of the wall, not a direction from the origin
+  Vec3 random(RenderContext& ctx, const Vec3&) const override {
+    double u1 = ctx.random->rand_interval(0.0, 1.0);
+    double u2 = ctx.random->rand_interval(0.0, 1.0);
+    double phi = 2.0 * kPi * u1;
+    double r_rand_sq = r0 * r0 + u2 * (r1 * r1 - r0 * r0);
+    double r_rand = std::sqrt(r_rand_sq);
+    double y_local = std::fabs(r1 - r0) < 1e-8 ? height * u2 : height / (r1 - r0) * (r_rand - r0);
+    Vec3 p_local(r_rand * std::cos(phi), y_local, r_rand * std::sin(phi));
+    return p_local + base;
+  }
+};
+
+// ---------------------------------------------------------------- object/cone.rs (the frustum)
+struct ConeFrustum : Node {
+  Group group;
+  // cone.rs:19-75: top disc, bottom disc (each only if its radius > 1e-4), side wall
+  ConeFrustum(const Vec3& base, double height, double top_radius, double bottom_radius, const std::shared_ptr<Material>& m) {
+    double y_base = base.y, y_top = base.y + height;
+    if (top_radius > 1e-4) group.push(std::make_shared<Disc>(Vec3(base.x, y_top, base.z), top_radius, Vec3(0.0, 1.0, 0.0), m));
+    if (bottom_radius > 1e-4) group.push(std::make_shared<Disc>(Vec3(base.x, y_base, base.z), bottom_radius, Vec3(0.0, -1.0, 0.0), m));
+    group.push(std::make_shared<ConeFrustumWall>(base, height, top_radius, bottom_radius, m));
+  }
+  int kind() const override { return K_CONE; }
+  bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
+    bool h = group.hit(ctx, ray, ray_t, rec);
+    if (h) rec.leaf_id = id;
+    return h;
+  }
+  const AABB& bounding_box() const override { return group.bounding_box(); }
+  double pdf_value(RenderContext& ctx, const Vec3& origin, const Vec3& direction) const override { return group.pdf_value(ctx, origin, direction); }
+  Vec3 random(RenderContext& ctx, const Vec3& origin) const override { return group.random(ctx, origin); }
+};
+
 // ---------------------------------------------------------------- object/translate.rs
 struct Translate : Node {
   NodeP object;
@@ -910,6 +1080,39 @@ struct Rotate : Node {
     if (!object->hit(ctx, rotated_r, ray_t, rec)) return false;
     rec.pt = rot.mul(rec.pt);
     rec.normal = rot.mul(rec.normal);
+    return true;
+  }
+  const AABB& bounding_box() const override { return bbox; }
+};
+
+// ---------------------------------------------------------------- object/scale.rs
+struct Scale : Node {
+  NodeP object;
+  Mat3 scale, inv;
+  AABB bbox;
+  // scale.rs:18-60
+  Scale(NodeP o, double sx, double sy, double sz) : object(std::move(o)) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) scale.m[i][j] = inv.m[i][j] = 0.0;
+    scale.m[0][0] = sx; scale.m[1][1] = sy; scale.m[2][2] = sz;
+    inv.m[0][0] = std::fabs(sx) > 1e-9 ? 1.0 / sx : kInf;
+    inv.m[1][1] = std::fabs(sy) > 1e-9 ? 1.0 / sy : kInf;
+    inv.m[2][2] = std::fabs(sz) > 1e-9 ? 1.0 / sz : kInf;
+    // scale.rs:62-91
+    const AABB& ob = object->bounding_box();
+    Interval ix(std::fmin(ob.x.min * sx, ob.x.max * sx), std::fmax(ob.x.min * sx, ob.x.max * sx));
+    Interval iy(std::fmin(ob.y.min * sy, ob.y.max * sy), std::fmax(ob.y.min * sy, ob.y.max * sy));
+    Interval iz(std::fmin(ob.z.min * sz, ob.z.max * sz), std::fmax(ob.z.min * sz, ob.z.max * sz));
+    bbox = AABB::pad_to_minimums(AABB{ix, iy, iz});
+  }
+  int kind() const override { return K_SCALE; }
+  // scale.rs:95-117: t is kept; the normal goes through the inverse matrix and is re-normalised
+  bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
+    Ray scaled_r(inv.mul(ray.origin), inv.mul(ray.direction), ray.time);
+    if (!object->hit(ctx, scaled_r, ray_t, rec)) return false;
+    rec.pt = scale.mul(rec.pt);
+    rec.normal = inv.mul(rec.normal);
+    rec.normal = rec.normal.unit();
     return true;
   }
   const AABB& bounding_box() const override { return bbox; }

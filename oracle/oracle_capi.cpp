@@ -175,6 +175,18 @@ int orc_rotate(OrcScene* s, int node, const double* axis, double deg) {
   CHECK_NODE(node);
   return add_node(s, std::make_shared<Rotate>(s->nodes[node], v3(axis), deg));
 }
+int orc_scale(OrcScene* s, int node, double sx, double sy, double sz) {
+  CHECK_NODE(node);
+  return add_node(s, std::make_shared<Scale>(s->nodes[node], sx, sy, sz));
+}
+int orc_disc(OrcScene* s, const double* center, double radius, const double* normal, int mat) {
+  CHECK_MAT(mat);
+  return add_node(s, std::make_shared<Disc>(v3(center), radius, v3(normal), s->materials[mat]));
+}
+int orc_cone_frustum(OrcScene* s, const double* base, double height, double top_radius, double bottom_radius, int mat) {
+  CHECK_MAT(mat);
+  return add_node(s, std::make_shared<ConeFrustum>(v3(base), height, top_radius, bottom_radius, s->materials[mat]));
+}
 int orc_constant_medium_color(OrcScene* s, int boundary, double density, double r, double g, double b) {
   CHECK_NODE(boundary);
   return add_node(s, std::make_shared<ConstantMedium>(s->nodes[boundary], density, std::make_shared<SolidColor>(Color(r, g, b))));
@@ -341,6 +353,10 @@ static void dump_rec(const Node* n, int32_t* kinds, int32_t* ids, double* boxes,
     case K_BOX:
       for (auto& c : static_cast<const BoxPrimitive*>(n)->group.nodes) dump_rec(c.get(), kinds, ids, boxes, cap, count);
       break;
+    case K_CONE:
+      for (auto& c : static_cast<const ConeFrustum*>(n)->group.nodes) dump_rec(c.get(), kinds, ids, boxes, cap, count);
+      break;
+    case K_SCALE: dump_rec(static_cast<const Scale*>(n)->object.get(), kinds, ids, boxes, cap, count); break;
     case K_TRANSLATE: dump_rec(static_cast<const Translate*>(n)->object.get(), kinds, ids, boxes, cap, count); break;
     case K_ROTATE: dump_rec(static_cast<const Rotate*>(n)->object.get(), kinds, ids, boxes, cap, count); break;
     case K_MEDIUM: dump_rec(static_cast<const ConstantMedium*>(n)->boundary.get(), kinds, ids, boxes, cap, count); break;

@@ -148,6 +148,9 @@ class Backend:
             "bvh": (i, [p, pi32, i]),
             "translate": (i, [p, i, pd]),
             "rotate": (i, [p, i, pd, d]),
+            "scale": (i, [p, i, d, d, d]),
+            "disc": (i, [p, pd, d, pd, i]),
+            "cone_frustum": (i, [p, pd, d, d, d, i]),
             "constant_medium_color": (i, [p, i, d, d, d, d]),
             "constant_medium_tex": (i, [p, i, d, i]),
             "scene_set_world": (i, [p, i]),
@@ -303,6 +306,15 @@ class Scene:
 
     def rotate(self, node, axis, degrees):
         return self._call("rotate", node, _vec3(axis), degrees)
+
+    def scale(self, node, sx, sy, sz):
+        return self._call("scale", node, sx, sy, sz)
+
+    def disc(self, center, radius, normal, mat):
+        return self._call("disc", _vec3(center), radius, _vec3(normal), mat)
+
+    def cone_frustum(self, base, height, top_radius, bottom_radius, mat):
+        return self._call("cone_frustum", _vec3(base), height, top_radius, bottom_radius, mat)
 
     def rotate_y(self, node, degrees):  # rotate.rs:87-89
         return self.rotate(node, (0.0, 1.0, 0.0), degrees)

@@ -63,6 +63,9 @@ struct chip_scene {
   DevBuf<nref_t> d_gchild;
   DevBuf<DTranslate> d_translates;
   DevBuf<DRotate> d_rotates;
+  DevBuf<DScale> d_scales;
+  DevBuf<DDisc> d_discs;
+  DevBuf<DCone> d_cones;
   DevBuf<DMedium> d_media;
   DevBuf<nref_t> d_xchain;
   DevBuf<DMaterial> d_materials;
@@ -103,7 +106,7 @@ struct chip_scene {
 
   void release_device() {
     d_bvh.release(); d_tnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release();
-    d_translates.release(); d_rotates.release(); d_media.release(); d_xchain.release(); d_materials.release();
+    d_translates.release(); d_rotates.release(); d_scales.release(); d_discs.release(); d_cones.release(); d_media.release(); d_xchain.release(); d_materials.release();
     d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
     pools[0].release();
     pools[1].release();
@@ -118,8 +121,8 @@ struct chip_scene {
 // Smallest traversal variant that covers the node families present in the flattened scene.
 static uint32_t scene_features(const Flat& F) {
   if (!F.media.empty()) return TF_QUADS | TF_XFORM | TF_MEDIA;
-  if (!F.translates.empty() || !F.rotates.empty()) return TF_QUADS | TF_XFORM;
-  if (!F.quads.empty() || !F.groups.empty()) return TF_QUADS;
+  if (!F.translates.empty() || !F.rotates.empty() || !F.scales.empty()) return TF_QUADS | TF_XFORM;
+  if (!F.quads.empty() || !F.groups.empty() || !F.discs.empty() || !F.cones.empty()) return TF_QUADS;
   return 0;
 }
 
@@ -753,6 +756,26 @@ int chip_rotate(chip_scene* s, int node, const double* axis, double deg) {
   s->committed = false;
   return s->host.nodes[s->host.make_rotate(s->host.handle[node], axis, deg)].id;
 }
+int chip_scale(chip_scene* s, int node, double sx, double sy, double sz) {
+  NEED_SCENE;
+  CHECK_NODE(node);
+  s->committed = false;
+  return s->host.nodes[s->host.make_scale(s->host.handle[node], sx, sy, sz)].id;
+}
+int chip_disc(chip_scene* s, const double* center, double radius, const double* normal, int mat) {
+  NEED_SCENE;
+  CHECK_MAT(mat);
+  if (!center || !normal) return fail("null argument");
+  s->committed = false;
+  return s->host.nodes[s->host.make_disc(center, radius, normal, mat, true)].id;
+}
+int chip_cone_frustum(chip_scene* s, const double* base, double height, double top_radius, double bottom_radius, int mat) {
+  NEED_SCENE;
+  CHECK_MAT(mat);
+  if (!base) return fail("null argument");
+  s->committed = false;
+  return s->host.nodes[s->host.make_cone_frustum(base, height, top_radius, bottom_radius, mat)].id;
+}
 int chip_constant_medium_color(chip_scene* s, int boundary, double density, double r, double g, double b) {
   NEED_SCENE;
   CHECK_NODE(boundary);
@@ -816,6 +839,9 @@ int chip_commit(chip_scene* s) {
   HIP_TRY(s->d_gchild.upload(F.gchild));
   HIP_TRY(s->d_translates.upload(F.translates));
   HIP_TRY(s->d_rotates.upload(F.rotates));
+  HIP_TRY(s->d_scales.upload(F.scales));
+  HIP_TRY(s->d_discs.upload(F.discs));
+  HIP_TRY(s->d_cones.upload(F.cones));
   HIP_TRY(s->d_media.upload(F.media));
   HIP_TRY(s->d_xchain.upload(F.xchain));
   // a material needs (u, v) only when an image texture is reachable from its texture (checker sub-textures included)
@@ -845,7 +871,8 @@ int chip_commit(chip_scene* s) {
   HIP_TRY(s->d_lights.upload(F.lights));
   DScene& D = s->dscene;
   D.bvh = s->d_bvh.p; D.tnodes = s->d_tnodes.p; D.spheres = s->d_spheres.p; D.quads = s->d_quads.p; D.groups = s->d_groups.p; D.gchild = s->d_gchild.p;
-  D.translates = s->d_translates.p; D.rotates = s->d_rotates.p; D.media = s->d_media.p; D.xchain = s->d_xchain.p;
+  D.translates = s->d_translates.p; D.rotates = s->d_rotates.p; D.scales = s->d_scales.p; D.discs = s->d_discs.p; D.cones = s->d_cones.p;
+  D.media = s->d_media.p; D.xchain = s->d_xchain.p;
   D.materials = s->d_materials.p; D.textures = s->d_textures.p; D.perlins = s->d_perlins.p; D.texels = s->d_texels.p;
   D.lights = s->d_lights.p;
   D.root = F.root;

@@ -17,6 +17,10 @@ enum : uint32_t {
   NK_EXIT_TRANSLATE = 7,  // traversal-stack marker: leave a Translate
   NK_EXIT_ROTATE = 8,     // traversal-stack marker: leave a Rotate
   NK_GROUP_CONT = 9,      // traversal-stack marker: continue a Group at the child index stored below it
+  NK_DISC = 10,
+  NK_CONE = 11,           // the side wall of a cone frustum
+  NK_SCALE = 12,
+  NK_EXIT_SCALE = 13,     // traversal-stack marker: leave a Scale
   NK_NONE = 15,
 };
 #define NREF(kind, idx) ((nref_t)(((uint32_t)(kind) << 28) | (uint32_t)(idx)))
@@ -69,6 +73,22 @@ struct alignas(16) DQuad {
   uint32_t seq;  // as DSphere::seq
 };
 
+struct alignas(8) DDisc {  // object/disc.rs
+  double c[3], n[3], r;
+  uint32_t mat;  // MATK_PACK
+  nref_t xform;
+  int32_t leaf_id;
+  uint32_t seq;
+};
+
+struct alignas(8) DCone {  // ConeFrustumWall, object/cone.rs:107-114
+  double base[3], h, r0, r1;  // r0 bottom radius, r1 top radius
+  uint32_t mat;  // MATK_PACK
+  nref_t xform;
+  int32_t leaf_id;
+  uint32_t seq;
+};
+
 struct DGroup {
   uint32_t first, count;  // children are gchild[first .. first+count)
 };
@@ -82,6 +102,13 @@ struct alignas(8) DTranslate {
 
 struct alignas(8) DRotate {
   double m[9];  // row-major rotation; the inverse is its transpose (rotate.rs:52-68)
+  nref_t child;
+  nref_t parent_xform;
+  uint32_t chain_first, chain_len;
+};
+
+struct alignas(8) DScale {
+  double m[9], inv[9];  // row-major scale matrix and the reference's inverse (scale.rs:18-46)
   nref_t child;
   nref_t parent_xform;
   uint32_t chain_first, chain_len;
@@ -118,10 +145,10 @@ struct DPerlin {
   int32_t perm_x[256], perm_y[256], perm_z[256];
 };
 
-enum : uint32_t { LK_SPHERE = 1, LK_QUAD = 2, LK_OTHER = 0 };
+enum : uint32_t { LK_SPHERE = 1, LK_QUAD = 2, LK_DISC = 3, LK_CONE_WALL = 4, LK_OTHER = 0 };
 struct DLight {
   uint32_t kind;
-  uint32_t index;  // into spheres / quads
+  uint32_t index;  // into spheres / quads / discs / cones
 };
 
 struct DCamera {  // Camera, camera.rs:202-231
@@ -140,6 +167,9 @@ struct DScene {
   const nref_t* gchild;
   const DTranslate* translates;
   const DRotate* rotates;
+  const DScale* scales;
+  const DDisc* discs;
+  const DCone* cones;
   const DMedium* media;
   const nref_t* xchain;
   const DMaterial* materials;

@@ -464,17 +464,70 @@ __device__ inline bool quad_hit(const DQuad& q, const TravRay& r, double tmin, d
   return true;
 }
 
+// disc.rs:111-131: plane hit with t inside [tmin, tmax] inclusive, then the radius test
+__device__ inline bool disc_hit(const DDisc& ds, const TravRay& r, double tmin, double tmax, double& t_out) {
+  V3 n = ld3(ds.n), c = ld3(ds.c);
+  double denominator = dot(r.d, n);
+  if (fabs(denominator) < 1e-8) return false;
+  double t = dot(c - r.o, n) / denominator;
+  if (!(tmin <= t && t <= tmax)) return false;
+  V3 pt = r.o + (t * r.d);
+  V3 v = pt - c;
+  if (len2(v) > ds.r * ds.r) return false;
+  t_out = t;
+  return true;
+}
+// cone.rs:164-243 (ConeFrustumWall::hit up to the choice of t)
+__device__ inline bool cone_hit(const DCone& cn, const TravRay& r, double tmin, double tmax, double& t_out) {
+  const double h = cn.h, r0 = cn.r0, r1 = cn.r1;
+  const double base_y = cn.base[1];
+  V3 lo = r.o - ld3(cn.base);
+  double ox = lo.x, oy = lo.y, oz = lo.z;
+  double dx = r.d.x, dy = r.d.y, dz = r.d.z;
+  double dr = r1 - r0;
+  double k = dr / h;
+  double a = dx * dx + dz * dz - k * k * dy * dy;
+  double b = 2.0 * (ox * dx + oz * dz - k * k * oy * dy - k * r0 * dy);
+  double c = ox * ox + oz * oz - (r0 * r0 + 2.0 * k * r0 * oy + k * k * oy * oy);
+  if (fabs(a) < 1e-8) return false;
+  double discriminant = b * b - 4.0 * a * c;
+  if (discriminant < 0.0) return false;
+  double sq = sqrt(discriminant);
+  double t = (-b - sq) / (2.0 * a);
+  if (!(tmin <= t && t <= tmax)) {
+    t = (-b + sq) / (2.0 * a);
+    if (!(tmin <= t && t <= tmax)) return false;
+  }
+  double hit_y = r.o.y + (t * r.d.y);  // the y of ray.at(t)
+  double y_min = base_y, y_max = base_y + h;
+  if (hit_y < y_min || hit_y > y_max) {
+    double t_other = (-b + sq) / (2.0 * a);
+    if (t_other == t) return false;
+    if (!(tmin <= t_other && t_other <= tmax)) return false;
+    double y_other = r.o.y + (t_other * r.d.y);
+    if (y_other < y_min || y_other > y_max) return false;
+    t = t_other;
+  }
+  t_out = t;
+  return true;
+}
+
 // Ordered traversal visits primitives in another order than the reference, so a candidate whose t
 // equals the current closest t exactly is decided by what the reference's order would have done:
 // the later primitive (depth-first position `seq`) replaces the earlier one iff its own interval test
 // is inclusive (quad.rs:152 `contains`), and loses iff it is exclusive (sphere.rs:110 `surrounds`).
-__device__ __noinline__ bool tie_wins(const DScene& S, nref_t cand, nref_t best) {
-  if (best == NREF_NONE) return true;
-  const bool cq = NREF_KIND(cand) == NK_QUAD, bq = NREF_KIND(best) == NK_QUAD;
-  const uint32_t sc = cq ? S.quads[NREF_INDEX(cand)].seq : S.spheres[NREF_INDEX(cand)].seq;
-  const uint32_t sb = bq ? S.quads[NREF_INDEX(best)].seq : S.spheres[NREF_INDEX(best)].seq;
-  return sc >= sb ? cq : !bq;
+__device__ inline uint32_t prim_seq(const DSphere* spheres, const DQuad* quads, const DDisc* discs, const DCone* cones, nref_t p) {
+  const uint32_t k = NREF_KIND(p), i = NREF_INDEX(p);
+  return k == NK_SPHERE ? spheres[i].seq : (k == NK_QUAD ? quads[i].seq : (k == NK_DISC ? discs[i].seq : cones[i].seq));
 }
+// (takes the tables rather than the scene: an out-of-line call with the whole DScene would put it on the stack)
+__device__ __noinline__ bool tie_wins_tables(const DSphere* spheres, const DQuad* quads, const DDisc* discs, const DCone* cones, nref_t cand, nref_t best) {
+  if (best == NREF_NONE) return true;
+  // quads, discs and cone walls accept t == max (`contains`); spheres do not (`surrounds`)
+  const bool c_incl = NREF_KIND(cand) != NK_SPHERE, b_incl = NREF_KIND(best) != NK_SPHERE;
+  return prim_seq(spheres, quads, discs, cones, cand) >= prim_seq(spheres, quads, discs, cones, best) ? c_incl : !b_incl;
+}
+__device__ inline bool tie_wins(const DScene& S, nref_t cand, nref_t best) { return tie_wins_tables(S.spheres, S.quads, S.discs, S.cones, cand, best); }
 // sphere.rs:99-121 with the interval's upper end inclusive (ties are then settled by tie_wins)
 template <typename SphereT>
 __device__ inline bool sphere_hit_incl(const SphereT& s, const TravRay& r, double tmin, double tmax, double& t_out) {
@@ -505,6 +558,10 @@ __device__ inline void ray_set_inv(TravRay& r) {
 __device__ inline void apply_xform(const DScene& S, nref_t x, V3& o, V3& d) {
   if (NREF_KIND(x) == NK_TRANSLATE) {
     o = o - ld3(S.translates[NREF_INDEX(x)].off);
+  } else if (NREF_KIND(x) == NK_SCALE) {  // scale.rs:97-98
+    const double* m = S.scales[NREF_INDEX(x)].inv;
+    o = mat_mul(m, o);
+    d = mat_mul(m, d);
   } else {
     const double* m = S.rotates[NREF_INDEX(x)].m;
     o = mat_mulT(m, o);
@@ -514,6 +571,7 @@ __device__ inline void apply_xform(const DScene& S, nref_t x, V3& o, V3& d) {
 __device__ inline void xform_chain(const DScene& S, nref_t x, uint32_t& first, uint32_t& n) {
   if (x == NREF_NONE) { first = 0; n = 0; }
   else if (NREF_KIND(x) == NK_TRANSLATE) { first = S.translates[NREF_INDEX(x)].chain_first; n = S.translates[NREF_INDEX(x)].chain_len; }
+  else if (NREF_KIND(x) == NK_SCALE) { first = S.scales[NREF_INDEX(x)].chain_first; n = S.scales[NREF_INDEX(x)].chain_len; }
   else { first = S.rotates[NREF_INDEX(x)].chain_first; n = S.rotates[NREF_INDEX(x)].chain_len; }
 }
 // Ray in the space below transform x: replay x's root->self chain on the world ray.
@@ -613,6 +671,14 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       double t, al, be;
       cnt.prim++;
       if (quad_hit(S.quads[idx], r, tmin, best_t, t, al, be)) { CHIP_TAKE(node, t, S.quads[idx].mat) }
+    } else if ((F & TF_QUADS) && kind == NK_DISC) {
+      double t;
+      cnt.prim++;
+      if (disc_hit(S.discs[idx], r, tmin, best_t, t)) { CHIP_TAKE(node, t, S.discs[idx].mat) }
+    } else if ((F & TF_QUADS) && kind == NK_CONE) {
+      double t;
+      cnt.prim++;
+      if (cone_hit(S.cones[idx], r, tmin, best_t, t)) { CHIP_TAKE(node, t, S.cones[idx].mat) }
     } else if ((F & TF_QUADS) && (kind == NK_GROUP || kind == NK_GROUP_CONT)) {
       // group.rs:44-54: children in order, each over the shrinking interval.  Primitive
       // children are tested inline; any other child is descended into, leaving a
@@ -634,6 +700,14 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
           double t, al, be;
           cnt.prim++;
           if (quad_hit(S.quads[NREF_INDEX(c)], r, tmin, best_t, t, al, be)) { CHIP_TAKE(c, t, S.quads[NREF_INDEX(c)].mat) }
+        } else if (ck == NK_DISC) {
+          double t;
+          cnt.prim++;
+          if (disc_hit(S.discs[NREF_INDEX(c)], r, tmin, best_t, t)) { CHIP_TAKE(c, t, S.discs[NREF_INDEX(c)].mat) }
+        } else if (ck == NK_CONE) {
+          double t;
+          cnt.prim++;
+          if (cone_hit(S.cones[NREF_INDEX(c)], r, tmin, best_t, t)) { CHIP_TAKE(c, t, S.cones[NREF_INDEX(c)].mat) }
         } else {
           if (pos + 1 < g.count) {
             st_push<ORD>(st, pos + 1);
@@ -664,8 +738,21 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       ray_set_inv<ORD>(r);
       node = t.child;
       continue;
-    } else if ((F & TF_XFORM) && (kind == NK_EXIT_TRANSLATE || kind == NK_EXIT_ROTATE)) {
-      nref_t px = kind == NK_EXIT_TRANSLATE ? S.translates[idx].parent_xform : S.rotates[idx].parent_xform;
+    } else if ((F & TF_XFORM) && kind == NK_SCALE) {
+      const DScale& t = S.scales[idx];
+      st_push<ORD>(st, NREF(NK_EXIT_SCALE, idx));
+      r.o = mat_mul(t.inv, r.o);
+      r.d = mat_mul(t.inv, r.d);
+      if (ORD && has_zero_component(r.d)) {  // a zero (or 0 * inf = NaN) component: start over, literally
+        st.redo = 1;
+        node = NREF_NONE;
+        return;
+      }
+      ray_set_inv<ORD>(r);
+      node = t.child;
+      continue;
+    } else if ((F & TF_XFORM) && (kind == NK_EXIT_TRANSLATE || kind == NK_EXIT_ROTATE || kind == NK_EXIT_SCALE)) {
+      nref_t px = kind == NK_EXIT_TRANSLATE ? S.translates[idx].parent_xform : (kind == NK_EXIT_ROTATE ? S.rotates[idx].parent_xform : S.scales[idx].parent_xform);
       ray_to_space(S, px, r.wo, r.wd, r.o, r.d);
       ray_set_inv<ORD>(r);
     } else if ((F & TF_MEDIA) && kind == NK_MEDIUM) {
@@ -717,6 +804,8 @@ __device__ inline double fast_rcp(double x) {
 }
 __device__ inline V3 fast_unit(V3 a) { return a * fast_rsqrt(len2(a)); }
 
+__device__ inline double rclamp(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }  // f64::clamp
+
 struct HitOut {
   V3 pt, n;
   double u, v;
@@ -744,7 +833,8 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
   nref_t x = NREF_NONE;
   V3 o = wo, d = wd;
   if (F & TF_XFORM) {
-    x = kind == NK_SPHERE ? S.spheres[idx].xform : (kind == NK_QUAD ? S.quads[idx].xform : S.media[idx].xform);
+    x = kind == NK_SPHERE ? S.spheres[idx].xform
+                          : (kind == NK_QUAD ? S.quads[idx].xform : (kind == NK_DISC ? S.discs[idx].xform : (kind == NK_CONE ? S.cones[idx].xform : S.media[idx].xform)));
     ray_to_space(S, x, wo, wd, o, d);
   }
   h.pt = o + (t * d);
@@ -770,6 +860,30 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
     h.n = h.front ? n : -n;
     h.mat = MATK_ID(q.mat);
     h.leaf_id = q.leaf_id;
+  } else if ((F & TF_QUADS) && kind == NK_DISC) {  // disc.rs:133-149
+    const DDisc& ds = S.discs[idx];
+    V3 local_pt = h.pt - ld3(ds.c);
+    h.u = (local_pt.x / ds.r + 1.0) * 0.5;
+    h.v = (local_pt.z / ds.r + 1.0) * 0.5;
+    V3 n = ld3(ds.n);
+    h.front = dot(d, n) < 0.0;
+    h.n = h.front ? n : -n;
+    h.mat = MATK_ID(ds.mat);
+    h.leaf_id = ds.leaf_id;
+  } else if ((F & TF_QUADS) && kind == NK_CONE) {  // cone.rs:245-287
+    const DCone& cn = S.cones[idx];
+    double k = (cn.r1 - cn.r0) / cn.h;
+    double hit_y_local = h.pt.y - cn.base[1];
+    double hit_radius = cn.r0 + k * hit_y_local;
+    V3 pt_local = h.pt - ld3(cn.base);
+    V3 outward = unit(mk(pt_local.x, k * hit_radius, pt_local.z));
+    double phi = atan2(pt_local.z, pt_local.x);
+    h.u = (phi + CHIP_PI) / (2.0 * CHIP_PI);
+    h.v = rclamp((pt_local.y - 0.0) / cn.h, 0.0, 1.0);
+    h.front = dot(d, outward) < 0.0;
+    h.n = h.front ? outward : -outward;
+    h.mat = MATK_ID(cn.mat);
+    h.leaf_id = cn.leaf_id;
   } else if (F & TF_MEDIA) {
     const DMedium& m = S.media[idx];
     h.n = mk(1.0, 0.0, 0.0);
@@ -786,6 +900,10 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
       nref_t xf = S.xchain[first + i - 1];
       if (NREF_KIND(xf) == NK_TRANSLATE) {
         h.pt = h.pt + ld3(S.translates[NREF_INDEX(xf)].off);
+      } else if (NREF_KIND(xf) == NK_SCALE) {  // scale.rs:104-113
+        const DScale& sc = S.scales[NREF_INDEX(xf)];
+        h.pt = mat_mul(sc.m, h.pt);
+        h.n = unit(mat_mul(sc.inv, h.n));
       } else {
         const double* m = S.rotates[NREF_INDEX(xf)].m;
         h.pt = mat_mul(m, h.pt);
@@ -825,7 +943,6 @@ __device__ inline double perlin_turbulence(const DPerlin& P, V3 pt, uint32_t dep
   }
   return fabs(acc);
 }
-__device__ inline double rclamp(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }  // f64::clamp
 __device__ inline V3 tex_value(const DScene& S, int tex, double u, double v, V3 pt) {
   for (int guard = 0; guard < 64; guard++) {
     const DTexture& T = S.textures[tex];
@@ -883,6 +1000,25 @@ __device__ inline double light_pdf_one(const DScene& S, const DLight& L, V3 orig
     double cosine = fabs(dot(dir, hn) / len(dir));
     return distance_squared / (cosine * q.area);
   }
+  if (L.kind == LK_DISC) {  // disc.rs:156-186
+    const DDisc& ds = S.discs[L.index];
+    double t;
+    if (!disc_hit(ds, r, 1e-4, INFINITY, t)) return 0.0;
+    V3 n = ld3(ds.n);
+    V3 hn = dot(dir, n) < 0.0 ? n : -n;
+    double dist_squared = t * t * len2(dir);
+    double cosine_abs = fabs(dot(hn, -dir));
+    if (cosine_abs < 1e-8) return 0.0;
+    double area = CHIP_PI * ds.r * ds.r;
+    return dist_squared / (cosine_abs * area);
+  }
+  if (L.kind == LK_CONE_WALL) {  // cone.rs:296-313: 1 / lateral area whatever the direction
+    const DCone& cn = S.cones[L.index];
+    double dr = cn.r1 - cn.r0;
+    double l = sqrt(cn.h * cn.h + dr * dr);
+    double area = CHIP_PI * (cn.r0 + cn.r1) * l;
+    return area > 1e-8 ? 1.0 / area : 0.0;
+  }
   return 0.0;  // Node::pdf_value default, object/mod.rs:59-61
 }
 __device__ inline V3 light_random_one(const DScene& S, const DLight& L, V3 origin, Rng& rng) {
@@ -904,6 +1040,28 @@ __device__ inline V3 light_random_one(const DScene& S, const DLight& L, V3 origi
     double r2 = rng.next();
     V3 p = ld3(q.q) + (r1 * ld3(q.u)) + (r2 * ld3(q.v));
     return p - origin;
+  }
+  if (L.kind == LK_DISC) {  // disc.rs:68-95,188-193
+    const DDisc& ds = S.discs[L.index];
+    double r_sq = sqrt(rng.next());
+    double phi = 2.0 * CHIP_PI * rng.next();
+    double x = r_sq * cos(phi) * ds.r;
+    double y = r_sq * sin(phi) * ds.r;
+    Onb uvw(ld3(ds.n));
+    V3 random_local_pt = (uvw.u * x) + (uvw.v * y);
+    V3 target = ld3(ds.c) + random_local_pt;
+    return target - origin;
+  }
+  if (L.kind == LK_CONE_WALL) {  // cone.rs:315-347: a point of the wall, not a direction from the origin
+    const DCone& cn = S.cones[L.index];
+    double u1 = 0.0 + (1.0 - 0.0) * rng.next();
+    double u2 = 0.0 + (1.0 - 0.0) * rng.next();
+    double phi = 2.0 * CHIP_PI * u1;
+    double r_rand_sq = cn.r0 * cn.r0 + u2 * (cn.r1 * cn.r1 - cn.r0 * cn.r0);
+    double r_rand = sqrt(r_rand_sq);
+    double y_local = fabs(cn.r1 - cn.r0) < 1e-8 ? cn.h * u2 : cn.h / (cn.r1 - cn.r0) * (r_rand - cn.r0);
+    V3 p_local = mk(r_rand * cos(phi), y_local, r_rand * sin(phi));
+    return p_local + ld3(cn.base);
   }
   return mk(1.0, 0.0, 0.0);  // Node::random default, object/mod.rs:63-65
 }

@@ -94,6 +94,9 @@ struct Flat {
   std::vector<nref_t> gchild;
   std::vector<DTranslate> translates;
   std::vector<DRotate> rotates;
+  std::vector<DScale> scales;
+  std::vector<DDisc> discs;
+  std::vector<DCone> cones;
   std::vector<DMedium> media;
   std::vector<nref_t> xchain;
   std::vector<DLight> lights;
@@ -229,6 +232,73 @@ struct HostScene {
     nodes[right].referenced = true;
     return add_node(std::move(n), user);
   }
+  // disc.rs:24-54
+  int make_disc(const double* c, double r, const double* nrm, int mat, bool user) {
+    HNode n;
+    n.kind = CHIP_NODE_DISC;
+    for (int i = 0; i < 3; i++) { n.a[i] = c[i]; n.a[3 + i] = nrm[i]; }
+    n.a[6] = r;
+    n.mat = mat;
+    const double delta = 1e-4;
+    double lo[3], hi[3];
+    for (int i = 0; i < 3; i++) {
+      double radius_i = std::fabs(nrm[i]) > 0.9 ? 0.0 : r;
+      double ext = radius_i + std::fabs(nrm[i]) * delta;
+      lo[i] = c[i] - ext;
+      hi[i] = c[i] + ext;
+    }
+    n.box = box_from_points(lo, hi);
+    return add_node(std::move(n), user);
+  }
+  // ConeFrustumWall::new, cone.rs:116-147
+  int make_cone_wall(const double* base, double h, double r1, double r0, int mat) {
+    HNode n;
+    n.kind = CHIP_NODE_CONE_WALL;
+    for (int i = 0; i < 3; i++) n.a[i] = base[i];
+    n.a[3] = h;
+    n.a[4] = r0;
+    n.a[5] = r1;
+    n.mat = mat;
+    double max_radius = std::fmax(r0, r1);
+    double lo[3] = {base[0] - max_radius, base[1], base[2] - max_radius};
+    double hi[3] = {base[0] + max_radius, base[1] + h, base[2] + max_radius};
+    n.box = box_from_points(lo, hi);
+    return add_node(std::move(n), false);
+  }
+  // ConeFrustum::new, cone.rs:19-75
+  int make_cone_frustum(const double* base, double h, double top_radius, double bottom_radius, int mat) {
+    std::vector<int> parts;
+    if (top_radius > 1e-4) {
+      double c[3] = {base[0], base[1] + h, base[2]}, nrm[3] = {0.0, 1.0, 0.0};
+      parts.push_back(make_disc(c, top_radius, nrm, mat, false));
+    }
+    if (bottom_radius > 1e-4) {
+      double c[3] = {base[0], base[1], base[2]}, nrm[3] = {0.0, -1.0, 0.0};
+      parts.push_back(make_disc(c, bottom_radius, nrm, mat, false));
+    }
+    parts.push_back(make_cone_wall(base, h, top_radius, bottom_radius, mat));
+    return make_group(parts, CHIP_NODE_CONE, true);
+  }
+  // scale.rs:18-91
+  int make_scale(int child, double sx, double sy, double sz) {
+    HNode n;
+    n.kind = CHIP_NODE_SCALE;
+    n.c0 = child;
+    const double sc[3] = {sx, sy, sz};
+    for (int i = 0; i < 3; i++) {
+      n.a[i] = sc[i];
+      n.a[3 + i] = std::fabs(sc[i]) > 1e-9 ? 1.0 / sc[i] : kInf;
+    }
+    const Box6& ob = nodes[child].box;
+    Box6 b;
+    for (int i = 0; i < 3; i++) {
+      b.v[2 * i] = std::fmin(ob.v[2 * i] * sc[i], ob.v[2 * i + 1] * sc[i]);
+      b.v[2 * i + 1] = std::fmax(ob.v[2 * i] * sc[i], ob.v[2 * i + 1] * sc[i]);
+    }
+    n.box = box_pad(b);
+    nodes[child].referenced = true;
+    return add_node(std::move(n), true);
+  }
   int make_translate(int child, const double* off) {  // translate.rs:15-22, aabb.rs:307-313 (no re-padding)
     HNode n;
     n.kind = CHIP_NODE_TRANSLATE;
@@ -348,6 +418,7 @@ struct HostScene {
       if (x == NREF_NONE) return;
       uint32_t first, n;
       if (NREF_KIND(x) == NK_TRANSLATE) { first = F.translates[NREF_INDEX(x)].chain_first; n = F.translates[NREF_INDEX(x)].chain_len; }
+      else if (NREF_KIND(x) == NK_SCALE) { first = F.scales[NREF_INDEX(x)].chain_first; n = F.scales[NREF_INDEX(x)].chain_len; }
       else { first = F.rotates[NREF_INDEX(x)].chain_first; n = F.rotates[NREF_INDEX(x)].chain_len; }
       out.assign(F.xchain.begin() + first, F.xchain.begin() + first + n);
     }
@@ -378,6 +449,33 @@ struct HostScene {
       return NREF(NK_QUAD, F.quads.size() - 1);
     }
 
+    nref_t emit_disc(const HNode& n, nref_t xform, int leaf_id) {
+      DDisc d;
+      std::memset(&d, 0, sizeof(d));
+      for (int i = 0; i < 3; i++) { d.c[i] = n.a[i]; d.n[i] = n.a[3 + i]; }
+      d.r = n.a[6];
+      d.mat = MATK_PACK(n.mat, H.materials[n.mat].kind);
+      d.xform = xform;
+      d.leaf_id = leaf_id;
+      d.seq = seq++;
+      F.discs.push_back(d);
+      return NREF(NK_DISC, F.discs.size() - 1);
+    }
+    nref_t emit_cone(const HNode& n, nref_t xform, int leaf_id) {
+      DCone c;
+      std::memset(&c, 0, sizeof(c));
+      for (int i = 0; i < 3; i++) c.base[i] = n.a[i];
+      c.h = n.a[3];
+      c.r0 = n.a[4];
+      c.r1 = n.a[5];
+      c.mat = MATK_PACK(n.mat, H.materials[n.mat].kind);
+      c.xform = xform;
+      c.leaf_id = leaf_id;
+      c.seq = seq++;
+      F.cones.push_back(c);
+      return NREF(NK_CONE, F.cones.size() - 1);
+    }
+
     // h: host index; xform: innermost transform ancestor; in_boundary: inside a medium's boundary subtree;
     // leaf_override: creation id reported for hits (a box reports its own id for its faces).
     nref_t emit(int h, nref_t xform, bool in_boundary, int leaf_override) {
@@ -385,9 +483,12 @@ struct HostScene {
       switch (n.kind) {
         case CHIP_NODE_SPHERE: return emit_sphere(n, xform, leaf_override >= 0 ? leaf_override : n.id);
         case CHIP_NODE_QUAD: return emit_quad(n, xform, leaf_override >= 0 ? leaf_override : n.id);
+        case CHIP_NODE_DISC: return emit_disc(n, xform, leaf_override >= 0 ? leaf_override : n.id);
+        case CHIP_NODE_CONE_WALL: return emit_cone(n, xform, leaf_override >= 0 ? leaf_override : n.id);
         case CHIP_NODE_GROUP:
+        case CHIP_NODE_CONE:
         case CHIP_NODE_BOX: {
-          int lo = n.kind == CHIP_NODE_BOX ? n.id : leaf_override;
+          int lo = (n.kind == CHIP_NODE_BOX || n.kind == CHIP_NODE_CONE) ? n.id : leaf_override;
           std::vector<nref_t> refs;
           refs.reserve(n.kids.size());
           for (int k : n.kids) refs.push_back(emit(k, xform, in_boundary, lo));
@@ -414,7 +515,8 @@ struct HostScene {
           return NREF(NK_BVH, idx);
         }
         case CHIP_NODE_TRANSLATE:
-        case CHIP_NODE_ROTATE: {
+        case CHIP_NODE_ROTATE:
+        case CHIP_NODE_SCALE: {
           std::vector<nref_t> chain;
           chain_of(xform, chain);
           nref_t self;
@@ -423,10 +525,14 @@ struct HostScene {
             idx = F.translates.size();
             F.translates.push_back(DTranslate{});
             self = NREF(NK_TRANSLATE, idx);
-          } else {
+          } else if (n.kind == CHIP_NODE_ROTATE) {
             idx = F.rotates.size();
             F.rotates.push_back(DRotate{});
             self = NREF(NK_ROTATE, idx);
+          } else {
+            idx = F.scales.size();
+            F.scales.push_back(DScale{});
+            self = NREF(NK_SCALE, idx);
           }
           chain.push_back(self);
           uint32_t cf = (uint32_t)F.xchain.size();
@@ -437,16 +543,24 @@ struct HostScene {
             t.parent_xform = xform;
             t.chain_first = cf;
             t.chain_len = (uint32_t)chain.size();
-          } else {
+          } else if (n.kind == CHIP_NODE_ROTATE) {
             DRotate& t = F.rotates[idx];
             for (int i = 0; i < 9; i++) t.m[i] = n.a[i];
+            t.parent_xform = xform;
+            t.chain_first = cf;
+            t.chain_len = (uint32_t)chain.size();
+          } else {
+            DScale& t = F.scales[idx];
+            for (int i = 0; i < 9; i++) t.m[i] = t.inv[i] = 0.0;
+            for (int i = 0; i < 3; i++) { t.m[4 * i] = n.a[i]; t.inv[4 * i] = n.a[3 + i]; }
             t.parent_xform = xform;
             t.chain_first = cf;
             t.chain_len = (uint32_t)chain.size();
           }
           nref_t c = emit(n.c0, self, in_boundary, leaf_override);
           if (n.kind == CHIP_NODE_TRANSLATE) F.translates[idx].child = c;
-          else F.rotates[idx].child = c;
+          else if (n.kind == CHIP_NODE_ROTATE) F.rotates[idx].child = c;
+          else F.scales[idx].child = c;
           return self;
         }
         case CHIP_NODE_MEDIUM: {
@@ -471,7 +585,9 @@ struct HostScene {
       DLight L;
       if (n.kind == CHIP_NODE_SPHERE) { L.kind = LK_SPHERE; L.index = NREF_INDEX(emit_sphere(n, NREF_NONE, n.id)); }
       else if (n.kind == CHIP_NODE_QUAD) { L.kind = LK_QUAD; L.index = NREF_INDEX(emit_quad(n, NREF_NONE, n.id)); }
-      else if (n.kind == CHIP_NODE_GROUP) throw std::runtime_error("nested Group inside the lights group is not supported");
+      else if (n.kind == CHIP_NODE_DISC) { L.kind = LK_DISC; L.index = NREF_INDEX(emit_disc(n, NREF_NONE, n.id)); }
+      else if (n.kind == CHIP_NODE_CONE_WALL) { L.kind = LK_CONE_WALL; L.index = NREF_INDEX(emit_cone(n, NREF_NONE, n.id)); }
+      else if (n.kind == CHIP_NODE_GROUP || n.kind == CHIP_NODE_CONE) throw std::runtime_error("nested Group inside the lights group is not supported");
       else { L.kind = LK_OTHER; L.index = 0; }  // Node::pdf_value / random defaults (object/mod.rs:59-65)
       F.lights.push_back(L);
     }
@@ -486,7 +602,7 @@ struct HostScene {
     if (lights >= 0) {
       F.has_lights = 1;
       const HNode& L = nodes[handle[lights]];
-      if (L.kind == CHIP_NODE_GROUP) {
+      if (L.kind == CHIP_NODE_GROUP || L.kind == CHIP_NODE_CONE) {  // a ConeFrustum samples as its Group (cone.rs:91-97)
         F.lights_is_group = 1;
         for (int k : L.kids) fl.emit_light(k);
       } else {
@@ -496,7 +612,7 @@ struct HostScene {
     }
     reorder_bvh_breadth_first(F);
     build_tnodes(F);
-    if (F.bvh.size() >= (1u << 28) || F.spheres.size() >= (1u << 28) || F.quads.size() >= (1u << 28))
+    if (F.bvh.size() >= (1u << 28) || F.spheres.size() >= (1u << 28) || F.quads.size() >= (1u << 28) || F.discs.size() >= (1u << 28) || F.cones.size() >= (1u << 28))
       throw std::runtime_error("scene too large for 28-bit node indices");
   }
 
@@ -546,6 +662,7 @@ struct HostScene {
     for (nref_t& c : F.gchild) c = remap(c);
     for (DTranslate& t : F.translates) t.child = remap(t.child);
     for (DRotate& t : F.rotates) t.child = remap(t.child);
+    for (DScale& t : F.scales) t.child = remap(t.child);
     for (DMedium& m : F.media) m.boundary = remap(m.boundary);
   }
 
@@ -744,11 +861,13 @@ struct HostScene {
         dump(n.c1, kinds, ids, boxes, cap, count);
         break;
       case CHIP_NODE_GROUP:
+      case CHIP_NODE_CONE:
       case CHIP_NODE_BOX:
         for (int k : n.kids) dump(k, kinds, ids, boxes, cap, count);
         break;
       case CHIP_NODE_TRANSLATE:
       case CHIP_NODE_ROTATE:
+      case CHIP_NODE_SCALE:
       case CHIP_NODE_MEDIUM: dump(n.c0, kinds, ids, boxes, cap, count); break;
       default: break;
     }

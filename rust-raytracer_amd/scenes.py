@@ -362,6 +362,69 @@ def lighted_sphere(sc, width=None, spp=None, depth=None, seed=1):
     return sc
 
 
+def lighted_cone_frustum(sc, width=None, spp=None, depth=None, seed=1):
+    """crates/cli/src/scene/lighted_cone_frustum.rs:12-80."""
+    rng = SceneRandom(seed)
+    per = sc.lambertian_tex(sc.tex_perlin_turbulence(4.0, 7, perlin_tables(rng)))
+    white = sc.diffuse_light_color(4.0, 4.0, 4.0)
+    blue = sc.diffuse_light_color(0.0, 0.0, 2.0)
+    world = [
+        sc.sphere((0.0, -1000.0, 0.0), 1000.0, per),
+        sc.cone_frustum((0.0, 1.5, 0.0), 2.0, 1.0, 2.0, per),
+        sc.quad((3.0, 1.0, -2.0), (2.0, 0.0, 0.0), (0.0, 2.0, 0.0), white),
+        sc.sphere((0.0, 7.0, 0.0), 2.0, blue),
+    ]
+    sc.set_world(sc.bvh(world))
+    sc.set_lights(None)
+    _camera(
+        sc, width, spp, depth, (400, 50, 50),
+        aspect_ratio=16.0 / 9.0, vertical_fov=20.0, look_from=(26.0, 6.0, 6.0), look_at=(0.0, 2.0, 0.0), up=(0.0, 1.0, 0.0),
+        defocus_angle=0.0, background=(0.0, 0.0, 0.0),
+    )
+    return sc
+
+
+def scad_shapes(sc, width=None, spp=None, depth=None, seed=1, light="disc"):
+    """The node vocabulary crates/openscad's interpreter adds to the book scenes (modules.rs:76-105 circle -> Disc,
+    165-232 cylinder -> ConeFrustum, 328-346 scale -> Scale), in the nesting it produces: scale / rotate / translate
+    chains around cylinders, cones, discs, spheres and boxes, lit by a disc (or by a cone frustum, whose side wall
+    has the reference's quirky pdf_value / random, cone.rs:296-347)."""
+    grey = sc.lambertian_color(0.73, 0.73, 0.73)
+    red = sc.lambertian_color(0.65, 0.05, 0.05)
+    green = sc.lambertian_color(0.12, 0.45, 0.15)
+    steel = sc.metal(0.8, 0.85, 0.88, 0.1)
+    glass = sc.dielectric(1.5)
+    lamp = sc.diffuse_light_color(12.0, 12.0, 12.0)
+    world = [
+        sc.quad((-8.0, 0.0, -8.0), (16.0, 0.0, 0.0), (0.0, 0.0, 16.0), grey),             # floor
+        sc.quad((-8.0, 0.0, -8.0), (16.0, 0.0, 0.0), (0.0, 10.0, 0.0), green),            # back wall
+        sc.cone_frustum((-3.0, 0.0, 0.0), 3.0, 1.0, 1.0, red),                              # cylinder
+        sc.cone_frustum((3.0, 0.0, 1.0), 2.5, 0.0, 1.5, steel),                             # cone (no top disc)
+        sc.translate(sc.scale(sc.sphere((0.0, 0.0, 0.0), 1.0, glass), 1.5, 0.75, 1.0), (0.0, 0.75, 2.5)),   # ellipsoid
+        sc.translate(sc.rotate(sc.scale(sc.box((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), grey), 2.0, 1.0, 0.5), (0.0, 1.0, 0.0), 30.0),
+                     (0.0, 0.5, -2.5)),                                                     # scaled, rotated box
+        sc.scale(sc.translate(sc.cone_frustum((0.0, 0.0, 0.0), 1.0, 0.5, 1.0, green), (2.0, 0.0, -1.0)), 1.0, 2.0, -1.0),  # mirrored frustum
+        sc.translate(sc.rotate(sc.disc((0.0, 0.0, 0.0), 1.25, (0.0, 1.0, 0.0), steel), (1.0, 0.0, 0.0), 70.0), (-5.0, 2.0, -3.0)),  # tilted mirror disc
+    ]
+    if light == "disc":
+        light_node = sc.disc((0.0, 7.5, 0.0), 1.5, (0.0, -1.0, 0.0), lamp)
+    else:
+        light_node = sc.cone_frustum((0.0, 6.5, 0.0), 1.0, 0.75, 1.5, lamp)
+    world.append(light_node)
+    sc.set_world(sc.bvh(world))
+    sc.set_lights(light_node)
+    _camera(
+        sc, width, spp, depth, (400, 64, 20),
+        aspect_ratio=4.0 / 3.0, vertical_fov=35.0, look_from=(0.0, 5.0, 16.0), look_at=(0.0, 2.0, 0.0), up=(0.0, 1.0, 0.0),
+        defocus_angle=0.0, background=(0.02, 0.02, 0.03),
+    )
+    return sc
+
+
+def scad_shapes_cone_light(sc, **kw):
+    return scad_shapes(sc, light="cone", **kw)
+
+
 def scad_lattice(sc, n=100, width=None, spp=None, depth=None, seed=1):
     """Synthetic scene with the shape crates/openscad's interpreter emits for nested `for` loops of
     `translate() sphere()` (crates/openscad/src/interpreter/modules.rs:139-163,274; mod.rs:190-194):
@@ -410,6 +473,9 @@ SCENES = {
     "perlin_spheres": perlin_spheres,
     "quads": quads,
     "lighted_sphere": lighted_sphere,
+    "lighted_cone_frustum": lighted_cone_frustum,
+    "scad_shapes": scad_shapes,
+    "scad_shapes_cone_light": scad_shapes_cone_light,
 }
 
 

@@ -25,6 +25,9 @@ ALL_SCENES = [
     "perlin_spheres",
     "quads",
     "lighted_sphere",
+    "lighted_cone_frustum",
+    "scad_shapes",
+    "scad_shapes_cone_light",
 ]
 
 

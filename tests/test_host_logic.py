@@ -9,7 +9,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-ALL_SCENES = ["random_spheres", "final", "cornell_box", "cornell_box_smoke", "three_spheres", "checkered_spheres", "earth", "perlin_spheres", "quads", "lighted_sphere"]
+ALL_SCENES = ["random_spheres", "final", "cornell_box", "cornell_box_smoke", "three_spheres", "checkered_spheres", "earth", "perlin_spheres", "quads", "lighted_sphere",
+              "lighted_cone_frustum", "scad_shapes", "scad_shapes_cone_light"]
 
 
 def test_library_exports_every_declared_symbol(gpu_lib):

@@ -86,3 +86,89 @@ def test_quads_scene_equals_brute_force(pkg, oracle):
     assert np.array_equal(hits["leaf_id"][m], best[m])
     assert np.abs(hits["t"][m] - best_t[m]).max() <= 1e-9 * np.abs(best_t[m]).max()
     assert np.abs(hits["u"][m]).max() <= 1.0 and hits["u"][m].min() >= 0.0
+
+
+def test_disc_cone_scale_equal_numpy(pkg, oracle):
+    """Disc, cone-frustum wall and Scale of the oracle against formulas written directly in numpy: an ellipsoid
+    (Scale of a unit sphere, then Translate), a frustum (two discs + wall) and a free disc in one Group."""
+    sx, sy, sz = 1.5, 0.75, 2.0
+    ell_c = np.array([0.5, 1.0, -1.0])
+    base, h, r_top, r_bot = np.array([-3.0, 0.0, 0.5]), 2.0, 0.5, 1.25
+    dc, dr, dn = np.array([3.0, 1.0, 0.0]), 1.0, np.array([0.0, 0.0, 1.0])
+    sc = oracle.new_scene()
+    m = sc.lambertian_color(0.5, 0.5, 0.5)
+    nodes = [
+        sc.translate(sc.scale(sc.sphere((0, 0, 0), 1.0, m), sx, sy, sz), tuple(ell_c)),
+        sc.cone_frustum(tuple(base), h, r_top, r_bot, m),
+        sc.disc(tuple(dc), dr, tuple(dn), m),
+    ]
+    sc.set_world(sc.group(nodes))
+    sc.set_camera(image_width=8, samples_per_pixel=1, max_depth=1)
+    sc.commit()
+    rng = np.random.default_rng(3)
+    n = 20000
+    o = rng.uniform(-6, 6, (n, 3))
+    d = rng.uniform(-4, 4, (n, 3)) - o * 0.5
+    hits = sc.trace_rays(o, d, None, seed=1)
+    tmin = 0.001
+    INF = np.inf
+
+    def first_in_range(t0, t1):
+        return np.where(t0 > tmin, t0, np.where(t1 > tmin, t1, INF))
+
+    # ellipsoid: unit sphere in the space x / s
+    s = np.array([sx, sy, sz])
+    oo, dd = (o - ell_c) / s, d / s
+    a = (dd * dd).sum(-1); hb = -(oo * dd).sum(-1); c = (oo * oo).sum(-1) - 1.0
+    disc = hb * hb - a * c
+    sq = np.sqrt(np.maximum(disc, 0))
+    t_ell = np.where(disc >= 0, first_in_range((hb - sq) / a, (hb + sq) / a), INF)
+    # discs (plane hit inside the radius, t >= tmin)
+    def disc_t(center, radius, normal):
+        den = d @ normal
+        t = ((center - o) @ normal) / np.where(np.abs(den) < 1e-8, np.nan, den)
+        p = o + t[:, None] * d
+        ok = (t >= tmin) & (((p - center) ** 2).sum(-1) <= radius * radius)
+        return np.where(ok, t, INF)
+    t_disc = disc_t(dc, dr, dn)
+    t_top = disc_t(base + np.array([0, h, 0]), r_top, np.array([0.0, 1.0, 0.0]))
+    t_bot = disc_t(base, r_bot, np.array([0.0, -1.0, 0.0]))
+    # wall: radius r(y) = r_bot + k y; candidates in the reference's order, cone.rs:204-243
+    lo = o - base
+    k = (r_top - r_bot) / h
+    A = d[:, 0] ** 2 + d[:, 2] ** 2 - k * k * d[:, 1] ** 2
+    Bq = 2.0 * (lo[:, 0] * d[:, 0] + lo[:, 2] * d[:, 2] - k * k * lo[:, 1] * d[:, 1] - k * r_bot * d[:, 1])
+    Cq = lo[:, 0] ** 2 + lo[:, 2] ** 2 - (r_bot + k * lo[:, 1]) ** 2
+    D = Bq * Bq - 4 * A * Cq
+    sqD = np.sqrt(np.maximum(D, 0))
+    ta, tb = (-Bq - sqD) / (2 * A), (-Bq + sqD) / (2 * A)
+    def y_ok(t):
+        y = lo[:, 1] + t * d[:, 1]
+        return (y >= 0) & (y <= h)
+    first = np.where(ta >= tmin, ta, np.where(tb >= tmin, tb, INF))
+    t_wall = np.where(np.isfinite(first) & y_ok(first), first, np.where((first != tb) & (tb >= tmin) & y_ok(tb), tb, INF))
+    t_wall = np.where((D >= 0) & (np.abs(A) >= 1e-8), t_wall, INF)
+    t_all = np.stack([t_ell, t_top, t_bot, t_wall, t_disc], axis=1)
+    best = t_all.argmin(axis=1)
+    t = t_all[np.arange(n), best]
+    hit_np = np.isfinite(t)
+    # rays within rounding of a rim or a tangent are ambiguous between the two computations
+    sorted_t = np.sort(t_all, axis=1)
+    clear = (np.abs(D) > 1e-9) & (np.abs(disc) > 1e-9)
+    assert (clear.mean() > 0.99) and hit_np.mean() > 0.1
+    assert np.array_equal((hits["hit"] == 1)[clear], hit_np[clear])
+    mk = clear & hit_np
+    assert np.abs(hits["t"][mk] - t[mk]).max() <= 1e-9 * (1 + np.abs(t[mk]).max())
+    # surface invariants of the reported points and normals
+    p = hits["pt"]; nrm = hits["normal"]
+    e = mk & (best == 0)
+    q = (p[e] - ell_c) / s
+    assert np.abs((q * q).sum(-1) - 1.0).max() < 1e-9
+    g = q / s
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    assert np.abs(np.abs((g * nrm[e]).sum(-1)) - 1.0).max() < 1e-9      # normal along the ellipsoid's gradient
+    w = mk & (best == 3)
+    pl = p[w] - base
+    assert np.abs(np.hypot(pl[:, 0], pl[:, 2]) - (r_bot + k * pl[:, 1])).max() < 1e-9
+    assert np.abs(np.linalg.norm(nrm[mk], axis=1) - 1.0).max() < 1e-12
+    assert ((nrm[mk] * d[mk]).sum(-1) <= 0).all()                        # set_face_normal: against the ray
