@@ -120,9 +120,11 @@ struct chip_scene {
 
 // Smallest traversal variant that covers the node families present in the flattened scene.
 static uint32_t scene_features(const Flat& F) {
-  if (!F.media.empty()) return TF_QUADS | TF_XFORM | TF_MEDIA;
-  if (!F.translates.empty() || !F.rotates.empty() || !F.scales.empty()) return TF_QUADS | TF_XFORM;
-  if (!F.quads.empty() || !F.groups.empty() || !F.discs.empty() || !F.cones.empty()) return TF_QUADS;
+  const uint32_t ext = (!F.discs.empty() || !F.cones.empty() || !F.scales.empty()) ? (TF_QUADS | TF_XFORM | TF_EXT) : 0u;
+  if (!F.media.empty()) return TF_QUADS | TF_XFORM | TF_MEDIA | ext;
+  if (ext) return ext;
+  if (!F.translates.empty() || !F.rotates.empty()) return TF_QUADS | TF_XFORM;
+  if (!F.quads.empty() || !F.groups.empty()) return TF_QUADS;
   return 0;
 }
 
@@ -275,8 +277,13 @@ static void launch_extend_t(const chip_scene* s, const PathPool& P, const Extend
 static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce) {
   if (feat & TF_MEDIA) {
     const ExtendPlan p = plan_extend(s, feat, false);
-    if (p.cache) launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, true, false>(s, P, p, n_live_upper, st, B, bounce, 0);
-    else launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, false, false>(s, P, p, n_live_upper, st, B, bounce, 0);
+    if (feat & TF_EXT) {
+      if (p.cache) launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT, true, false>(s, P, p, n_live_upper, st, B, bounce, 0);
+      else launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT, false, false>(s, P, p, n_live_upper, st, B, bounce, 0);
+    } else {
+      if (p.cache) launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, true, false>(s, P, p, n_live_upper, st, B, bounce, 0);
+      else launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, false, false>(s, P, p, n_live_upper, st, B, bounce, 0);
+    }
     return;
   }
   const ExtendPlan lit = plan_extend(s, feat, true);
@@ -288,7 +295,8 @@ static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat,
   switch (feat) {
     case 0: CHIP_EXT(0); break;
     case TF_QUADS: CHIP_EXT(TF_QUADS); break;
-    default: CHIP_EXT(TF_QUADS | TF_XFORM); break;
+    case TF_QUADS | TF_XFORM: CHIP_EXT(TF_QUADS | TF_XFORM); break;
+    default: CHIP_EXT(TF_QUADS | TF_XFORM | TF_EXT); break;
   }
 #undef CHIP_EXT
 }
@@ -416,12 +424,17 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       launch_extend(s, P, feat, L.live_upper, L.st, B, bounce);
       if (time_kernels) (void)hipEventRecord(new_event(), L.st);
       n_trace_launches++;
-      if (lean) {
-        if (exact_shading) hipLaunchKernelGGL((k_shade_tiles<false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
-        else hipLaunchKernelGGL((k_shade_tiles<true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
-      } else {
-        if (exact_shading) hipLaunchKernelGGL((k_shade_tiles<false, false>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
-        else hipLaunchKernelGGL((k_shade_tiles<true, false>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
+      {
+        const bool ext = (feat & TF_EXT) != 0;
+#define CHIP_SHADE(FAST, LEAN, EXT) hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce)
+        if (lean) {
+          if (exact_shading) CHIP_SHADE(false, true, false); else CHIP_SHADE(true, true, false);
+        } else if (ext) {
+          if (exact_shading) CHIP_SHADE(false, false, true); else CHIP_SHADE(true, false, true);
+        } else {
+          if (exact_shading) CHIP_SHADE(false, false, false); else CHIP_SHADE(true, false, false);
+        }
+#undef CHIP_SHADE
       }
       if (time_kernels) (void)hipEventRecord(new_event(), L.st);
       L.bounce++;
@@ -993,7 +1006,9 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
       case 0: CHIP_TRACE(0); break;
       case TF_QUADS: CHIP_TRACE(TF_QUADS); break;
       case TF_QUADS | TF_XFORM: CHIP_TRACE(TF_QUADS | TF_XFORM); break;
-      default: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA); break;
+      case TF_QUADS | TF_XFORM | TF_MEDIA: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA); break;
+      case TF_QUADS | TF_XFORM | TF_EXT: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_EXT); break;
+      default: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT); break;
     }
 #undef CHIP_TRACE
     if ((e = hipGetLastError()) != hipSuccess) break;

@@ -554,11 +554,16 @@ __device__ inline void ray_set_inv(TravRay& r) {
   else r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
   r.dd = len2(r.d);
 }
-// translate.rs:28 / rotate.rs:137-138
+// Scene features a traversal / shade instantiation handles (scenes lacking a feature run a leaner variant):
+// quads & groups | Translate & Rotate | ConstantMedium | discs, cone walls & Scale
+enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4, TF_EXT = 8 };
+
+// translate.rs:28 / rotate.rs:137-138 / scale.rs:97-98
+template <bool EXT>
 __device__ inline void apply_xform(const DScene& S, nref_t x, V3& o, V3& d) {
   if (NREF_KIND(x) == NK_TRANSLATE) {
     o = o - ld3(S.translates[NREF_INDEX(x)].off);
-  } else if (NREF_KIND(x) == NK_SCALE) {  // scale.rs:97-98
+  } else if (EXT && NREF_KIND(x) == NK_SCALE) {
     const double* m = S.scales[NREF_INDEX(x)].inv;
     o = mat_mul(m, o);
     d = mat_mul(m, d);
@@ -568,22 +573,22 @@ __device__ inline void apply_xform(const DScene& S, nref_t x, V3& o, V3& d) {
     d = mat_mulT(m, d);
   }
 }
+template <bool EXT>
 __device__ inline void xform_chain(const DScene& S, nref_t x, uint32_t& first, uint32_t& n) {
   if (x == NREF_NONE) { first = 0; n = 0; }
   else if (NREF_KIND(x) == NK_TRANSLATE) { first = S.translates[NREF_INDEX(x)].chain_first; n = S.translates[NREF_INDEX(x)].chain_len; }
-  else if (NREF_KIND(x) == NK_SCALE) { first = S.scales[NREF_INDEX(x)].chain_first; n = S.scales[NREF_INDEX(x)].chain_len; }
+  else if (EXT && NREF_KIND(x) == NK_SCALE) { first = S.scales[NREF_INDEX(x)].chain_first; n = S.scales[NREF_INDEX(x)].chain_len; }
   else { first = S.rotates[NREF_INDEX(x)].chain_first; n = S.rotates[NREF_INDEX(x)].chain_len; }
 }
 // Ray in the space below transform x: replay x's root->self chain on the world ray.
+template <bool EXT>
 __device__ inline void ray_to_space(const DScene& S, nref_t x, V3 wo, V3 wd, V3& o, V3& d) {
   o = wo; d = wd;
   uint32_t first, n;
-  xform_chain(S, x, first, n);
-  for (uint32_t i = 0; i < n; i++) apply_xform(S, S.xchain[first + i], o, d);
+  xform_chain<EXT>(S, x, first, n);
+  for (uint32_t i = 0; i < n; i++) apply_xform<EXT>(S, S.xchain[first + i], o, d);
 }
 
-// Scene features a traversal instantiation handles (scenes lacking a feature run a leaner variant).
-enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4 };  // quads & groups | Translate & Rotate | ConstantMedium
 
 // Closest hit below `start` for the ray in r, over (tmin, best_t]; best_t doubles as
 // the shrinking interval maximum of bvh.rs:66-70 / group.rs:47-52.
@@ -606,11 +611,12 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
 
 // A medium's boundary subtree (constant_medium.rs:42-45) is traversed on the same stack; it may hold
 // anything except another medium.
+template <bool EXT>
 __device__ __noinline__ void traverse_boundary(const DScene& S, nref_t start, TravRay& r, double tmin, double& best_t, nref_t& best,
                                                Rng& rng, TravStack& st, TravCounters& cnt) {
   nref_t node = start;
   NodeCache none{0, 0, 0, 0, 0, 0};
-  traverse<TF_QUADS | TF_XFORM, false, false, false>(S, none, node, r, tmin, best_t, best, rng, st, st.sp, cnt);
+  traverse<TF_QUADS | TF_XFORM | (EXT ? TF_EXT : 0u), false, false, false>(S, none, node, r, tmin, best_t, best, rng, st, st.sp, cnt);
 }
 
 template <uint32_t F, bool YIELD, bool CACHE, bool ORD>
@@ -671,11 +677,11 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       double t, al, be;
       cnt.prim++;
       if (quad_hit(S.quads[idx], r, tmin, best_t, t, al, be)) { CHIP_TAKE(node, t, S.quads[idx].mat) }
-    } else if ((F & TF_QUADS) && kind == NK_DISC) {
+    } else if ((F & TF_EXT) && kind == NK_DISC) {
       double t;
       cnt.prim++;
       if (disc_hit(S.discs[idx], r, tmin, best_t, t)) { CHIP_TAKE(node, t, S.discs[idx].mat) }
-    } else if ((F & TF_QUADS) && kind == NK_CONE) {
+    } else if ((F & TF_EXT) && kind == NK_CONE) {
       double t;
       cnt.prim++;
       if (cone_hit(S.cones[idx], r, tmin, best_t, t)) { CHIP_TAKE(node, t, S.cones[idx].mat) }
@@ -700,11 +706,11 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
           double t, al, be;
           cnt.prim++;
           if (quad_hit(S.quads[NREF_INDEX(c)], r, tmin, best_t, t, al, be)) { CHIP_TAKE(c, t, S.quads[NREF_INDEX(c)].mat) }
-        } else if (ck == NK_DISC) {
+        } else if ((F & TF_EXT) && ck == NK_DISC) {
           double t;
           cnt.prim++;
           if (disc_hit(S.discs[NREF_INDEX(c)], r, tmin, best_t, t)) { CHIP_TAKE(c, t, S.discs[NREF_INDEX(c)].mat) }
-        } else if (ck == NK_CONE) {
+        } else if ((F & TF_EXT) && ck == NK_CONE) {
           double t;
           cnt.prim++;
           if (cone_hit(S.cones[NREF_INDEX(c)], r, tmin, best_t, t)) { CHIP_TAKE(c, t, S.cones[NREF_INDEX(c)].mat) }
@@ -738,7 +744,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       ray_set_inv<ORD>(r);
       node = t.child;
       continue;
-    } else if ((F & TF_XFORM) && kind == NK_SCALE) {
+    } else if ((F & TF_EXT) && kind == NK_SCALE) {
       const DScale& t = S.scales[idx];
       st_push<ORD>(st, NREF(NK_EXIT_SCALE, idx));
       r.o = mat_mul(t.inv, r.o);
@@ -751,9 +757,10 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       ray_set_inv<ORD>(r);
       node = t.child;
       continue;
-    } else if ((F & TF_XFORM) && (kind == NK_EXIT_TRANSLATE || kind == NK_EXIT_ROTATE || kind == NK_EXIT_SCALE)) {
-      nref_t px = kind == NK_EXIT_TRANSLATE ? S.translates[idx].parent_xform : (kind == NK_EXIT_ROTATE ? S.rotates[idx].parent_xform : S.scales[idx].parent_xform);
-      ray_to_space(S, px, r.wo, r.wd, r.o, r.d);
+    } else if ((F & TF_XFORM) && (kind == NK_EXIT_TRANSLATE || kind == NK_EXIT_ROTATE || ((F & TF_EXT) && kind == NK_EXIT_SCALE))) {
+      nref_t px = kind == NK_EXIT_TRANSLATE ? S.translates[idx].parent_xform
+                                            : ((!(F & TF_EXT) || kind == NK_EXIT_ROTATE) ? S.rotates[idx].parent_xform : S.scales[idx].parent_xform);
+      ray_to_space<(F & TF_EXT) != 0>(S, px, r.wo, r.wd, r.o, r.d);
       ray_set_inv<ORD>(r);
     } else if ((F & TF_MEDIA) && kind == NK_MEDIUM) {
       // constant_medium.rs:41-80
@@ -762,9 +769,9 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       bool hit_medium = false;
       double t1 = INFINITY, t2 = INFINITY;
       nref_t b1 = NREF_NONE, b2 = NREF_NONE;
-      traverse_boundary(S, m.boundary, r, -INFINITY, t1, b1, rng, st, cnt);
+      traverse_boundary<(F & TF_EXT) != 0>(S, m.boundary, r, -INFINITY, t1, b1, rng, st, cnt);
       if (b1 != NREF_NONE) {
-        traverse_boundary(S, m.boundary, r, t1 + 0.0001, t2, b2, rng, st, cnt);
+        traverse_boundary<(F & TF_EXT) != 0>(S, m.boundary, r, t1 + 0.0001, t2, b2, rng, st, cnt);
         if (b2 != NREF_NONE) {
           if (t1 < tmin) t1 = tmin;
           if (t2 > best_t) t2 = best_t;
@@ -784,7 +791,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       r.best_mat = hit_medium ? m.mat : outer_mat;
     }
     node = st_pop<ORD>(st, base, r.capf);
-    if (YIELD && may_yield && __popcll(__ballot(1)) < CHIP_REFILL_THRESH) break;
+    if (YIELD && ORD && may_yield && __popcll(__ballot(1)) < CHIP_REFILL_THRESH) break;  // (the literal form is too heavy to gain from refills)
   }
 #undef CHIP_TAKE
 }
@@ -833,9 +840,12 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
   nref_t x = NREF_NONE;
   V3 o = wo, d = wd;
   if (F & TF_XFORM) {
-    x = kind == NK_SPHERE ? S.spheres[idx].xform
-                          : (kind == NK_QUAD ? S.quads[idx].xform : (kind == NK_DISC ? S.discs[idx].xform : (kind == NK_CONE ? S.cones[idx].xform : S.media[idx].xform)));
-    ray_to_space(S, x, wo, wd, o, d);
+    if (kind == NK_SPHERE) x = S.spheres[idx].xform;
+    else if (kind == NK_QUAD) x = S.quads[idx].xform;
+    else if ((F & TF_EXT) && kind == NK_DISC) x = S.discs[idx].xform;
+    else if ((F & TF_EXT) && kind == NK_CONE) x = S.cones[idx].xform;
+    else x = S.media[idx].xform;
+    ray_to_space<(F & TF_EXT) != 0>(S, x, wo, wd, o, d);
   }
   h.pt = o + (t * d);
   if (kind == NK_SPHERE) {
@@ -860,7 +870,7 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
     h.n = h.front ? n : -n;
     h.mat = MATK_ID(q.mat);
     h.leaf_id = q.leaf_id;
-  } else if ((F & TF_QUADS) && kind == NK_DISC) {  // disc.rs:133-149
+  } else if ((F & TF_EXT) && kind == NK_DISC) {  // disc.rs:133-149
     const DDisc& ds = S.discs[idx];
     V3 local_pt = h.pt - ld3(ds.c);
     h.u = (local_pt.x / ds.r + 1.0) * 0.5;
@@ -870,7 +880,7 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
     h.n = h.front ? n : -n;
     h.mat = MATK_ID(ds.mat);
     h.leaf_id = ds.leaf_id;
-  } else if ((F & TF_QUADS) && kind == NK_CONE) {  // cone.rs:245-287
+  } else if ((F & TF_EXT) && kind == NK_CONE) {  // cone.rs:245-287
     const DCone& cn = S.cones[idx];
     double k = (cn.r1 - cn.r0) / cn.h;
     double hit_y_local = h.pt.y - cn.base[1];
@@ -895,12 +905,12 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
   }
   if (F & TF_XFORM) {
     uint32_t first, n;
-    xform_chain(S, x, first, n);
+    xform_chain<(F & TF_EXT) != 0>(S, x, first, n);
     for (uint32_t i = n; i > 0; i--) {
       nref_t xf = S.xchain[first + i - 1];
       if (NREF_KIND(xf) == NK_TRANSLATE) {
         h.pt = h.pt + ld3(S.translates[NREF_INDEX(xf)].off);
-      } else if (NREF_KIND(xf) == NK_SCALE) {  // scale.rs:104-113
+      } else if ((F & TF_EXT) && NREF_KIND(xf) == NK_SCALE) {  // scale.rs:104-113
         const DScale& sc = S.scales[NREF_INDEX(xf)];
         h.pt = mat_mul(sc.m, h.pt);
         h.n = unit(mat_mul(sc.inv, h.n));
@@ -978,6 +988,7 @@ __device__ inline V3 tex_value(const DScene& S, int tex, double u, double v, V3 
 }
 
 // ------------------------------------------------------------------ light sampling (quad.rs:210-245, sphere.rs:85-95,143-170, group.rs:60-78)
+template <bool EXT>
 __device__ inline double light_pdf_one(const DScene& S, const DLight& L, V3 origin, V3 dir) {
   TravRay r;
   r.o = origin; r.d = dir; r.time = 0.0;  // Ray::new -> time 0
@@ -1000,7 +1011,7 @@ __device__ inline double light_pdf_one(const DScene& S, const DLight& L, V3 orig
     double cosine = fabs(dot(dir, hn) / len(dir));
     return distance_squared / (cosine * q.area);
   }
-  if (L.kind == LK_DISC) {  // disc.rs:156-186
+  if (EXT && L.kind == LK_DISC) {  // disc.rs:156-186
     const DDisc& ds = S.discs[L.index];
     double t;
     if (!disc_hit(ds, r, 1e-4, INFINITY, t)) return 0.0;
@@ -1012,7 +1023,7 @@ __device__ inline double light_pdf_one(const DScene& S, const DLight& L, V3 orig
     double area = CHIP_PI * ds.r * ds.r;
     return dist_squared / (cosine_abs * area);
   }
-  if (L.kind == LK_CONE_WALL) {  // cone.rs:296-313: 1 / lateral area whatever the direction
+  if (EXT && L.kind == LK_CONE_WALL) {  // cone.rs:296-313: 1 / lateral area whatever the direction
     const DCone& cn = S.cones[L.index];
     double dr = cn.r1 - cn.r0;
     double l = sqrt(cn.h * cn.h + dr * dr);
@@ -1021,6 +1032,7 @@ __device__ inline double light_pdf_one(const DScene& S, const DLight& L, V3 orig
   }
   return 0.0;  // Node::pdf_value default, object/mod.rs:59-61
 }
+template <bool EXT>
 __device__ inline V3 light_random_one(const DScene& S, const DLight& L, V3 origin, Rng& rng) {
   if (L.kind == LK_SPHERE) {
     const DSphere& s = S.spheres[L.index];
@@ -1041,7 +1053,7 @@ __device__ inline V3 light_random_one(const DScene& S, const DLight& L, V3 origi
     V3 p = ld3(q.q) + (r1 * ld3(q.u)) + (r2 * ld3(q.v));
     return p - origin;
   }
-  if (L.kind == LK_DISC) {  // disc.rs:68-95,188-193
+  if (EXT && L.kind == LK_DISC) {  // disc.rs:68-95,188-193
     const DDisc& ds = S.discs[L.index];
     double r_sq = sqrt(rng.next());
     double phi = 2.0 * CHIP_PI * rng.next();
@@ -1052,7 +1064,7 @@ __device__ inline V3 light_random_one(const DScene& S, const DLight& L, V3 origi
     V3 target = ld3(ds.c) + random_local_pt;
     return target - origin;
   }
-  if (L.kind == LK_CONE_WALL) {  // cone.rs:315-347: a point of the wall, not a direction from the origin
+  if (EXT && L.kind == LK_CONE_WALL) {  // cone.rs:315-347: a point of the wall, not a direction from the origin
     const DCone& cn = S.cones[L.index];
     double u1 = 0.0 + (1.0 - 0.0) * rng.next();
     double u2 = 0.0 + (1.0 - 0.0) * rng.next();
@@ -1065,19 +1077,21 @@ __device__ inline V3 light_random_one(const DScene& S, const DLight& L, V3 origi
   }
   return mk(1.0, 0.0, 0.0);  // Node::random default, object/mod.rs:63-65
 }
+template <bool EXT>
 __device__ inline double lights_pdf(const DScene& S, V3 origin, V3 dir) {
-  if (!S.lights_is_group) return light_pdf_one(S, S.lights[0], origin, dir);
+  if (!S.lights_is_group) return light_pdf_one<EXT>(S, S.lights[0], origin, dir);
   double weight = 1.0 / (double)S.n_lights;
   double sum = 0.0;
-  for (uint32_t i = 0; i < S.n_lights; i++) sum += weight * light_pdf_one(S, S.lights[i], origin, dir);
+  for (uint32_t i = 0; i < S.n_lights; i++) sum += weight * light_pdf_one<EXT>(S, S.lights[i], origin, dir);
   return sum;
 }
+template <bool EXT>
 __device__ inline V3 lights_random(const DScene& S, V3 origin, Rng& rng) {
-  if (!S.lights_is_group) return light_random_one(S, S.lights[0], origin, rng);
+  if (!S.lights_is_group) return light_random_one<EXT>(S, S.lights[0], origin, rng);
   if (S.n_lights == 0) return mk(0.0, 1.0, 0.0);
   uint32_t i = (uint32_t)(long long)(rng.next() * (double)S.n_lights);  // rand_int_interval(0, len)
   if (i >= S.n_lights) i = S.n_lights - 1;
-  return light_random_one(S, S.lights[i], origin, rng);
+  return light_random_one<EXT>(S, S.lights[i], origin, rng);
 }
 
 // ------------------------------------------------------------------ queue helpers (wave64 ballot + prefix popcount)
@@ -1375,7 +1389,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
 // otherwise the path's sample is written.
 // LEAN is the variant for scenes made only of spheres with solid-colour textures and no lights (no
 // transforms, quads, media, image / noise / checker textures or light sampling to carry in registers).
-template <uint32_t KIND, bool FAST, bool LEAN>
+template <uint32_t KIND, bool FAST, bool LEAN, bool EXT>
 __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, bool last_bounce, uint32_t slot,
                                  const PathHit& ph, V3 ro, V3 rd, double rtime) {
   bool cont = false;
@@ -1386,7 +1400,7 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
   const DMaterial& M = S.materials[MATK_ID(ph.info)];
   const bool has_lights = !LEAN && S.has_lights;
   HitOut hrec;
-  reconstruct<LEAN ? 0u : (TF_QUADS | TF_XFORM | TF_MEDIA), FAST>(S, leaf, ph.t, ro, rd, rtime, hrec, !LEAN && (M.flags & MF_NEEDS_UV) != 0);
+  reconstruct<LEAN ? 0u : (TF_QUADS | TF_XFORM | TF_MEDIA | (EXT ? TF_EXT : 0u)), FAST>(S, leaf, ph.t, ro, rd, rtime, hrec, !LEAN && (M.flags & MF_NEEDS_UV) != 0);
   const bool front = hrec.front;
   const V3 pt = hrec.pt;
   if (KIND == MK_DIFFUSE_LIGHT) {
@@ -1447,7 +1461,7 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
           ou = cross(ow, ov);
         }
         if (use_light) {
-          ndir = lights_random(S, pt, rng);
+          ndir = lights_random<EXT>(S, pt, rng);
         } else if (KIND == MK_LAMBERTIAN) {
           float r1 = (float)rng.next(), r2 = (float)rng.next();
           float sn, cs;
@@ -1462,7 +1476,7 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
         if (KIND == MK_LAMBERTIAN) cos_n = (use_light || has_lights) ? dot(fast_unit(ndir), ow) : local_z;
         double mat_pdf = KIND == MK_LAMBERTIAN ? fmax(cos_n * (1.0 / CHIP_PI), 0.0) : 1.0 / (4.0 * CHIP_PI);
         double pv = mat_pdf;
-        if (has_lights) pv = 0.5 * lights_pdf(S, pt, ndir) + 0.5 * mat_pdf;
+        if (has_lights) pv = 0.5 * lights_pdf<EXT>(S, pt, ndir) + 0.5 * mat_pdf;
         if (pv < 0.05) {
           terminal = true;
         } else {
@@ -1473,7 +1487,7 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
         }
       } else {
       Onb uvw(nrm);                                    // cosine.rs:10-14 (unused for Isotropic)
-      if (use_light) ndir = lights_random(S, pt, rng);
+      if (use_light) ndir = lights_random<EXT>(S, pt, rng);
       else if (KIND == MK_LAMBERTIAN) ndir = uvw.local(random_cosine_direction(rng));  // cosine.rs:24-27
       else ndir = random_unit<false>(rng);                                            // probability_density_function/sphere.rs:24-26
       double mat_pdf;
@@ -1481,7 +1495,7 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
       else mat_pdf = 1.0 / (4.0 * CHIP_PI);                                              // sphere.rs:20-22
       double pv = mat_pdf;
       if (has_lights) {  // mixture.rs:20-24
-        double v0 = 0.5 * lights_pdf(S, pt, ndir);
+        double v0 = 0.5 * lights_pdf<EXT>(S, pt, ndir);
         double v1 = 0.5 * mat_pdf;
         pv = v0 + v1;
       }
@@ -1526,7 +1540,7 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
 // with one global atomic per tile.  Binning per tile instead of through global per-material queues saves
 // a pass over the hit records and the queue traffic.
 #define CHIP_SHADE_TILE 1024
-template <bool FAST, bool LEAN>
+template <bool FAST, bool LEAN, bool EXT>
 __global__ void __launch_bounds__(CHIP_BLOCK) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce) {
   const uint32_t* q_in = P.q_live[bounce & 1];
   uint32_t* q_out = P.q_live[(bounce + 1) & 1];
@@ -1575,7 +1589,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade_tiles(DScene S, PathPool P
     V3 ro, rd;                                                                                                   \
     double rtime;                                                                                                \
     segment_ray(S, P, B, bounce, slot, ro, rd, rtime);                                                           \
-    if (shade_hit<KIND, FAST, LEAN>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime)) s_a[atomicAdd(&s_live, 1u)] = slot; \
+    if (shade_hit<KIND, FAST, LEAN, EXT>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime)) s_a[atomicAdd(&s_live, 1u)] = slot; \
   }
     CHIP_SHADE_BIN(MK_LAMBERTIAN)
     CHIP_SHADE_BIN(MK_METAL)
