@@ -111,6 +111,10 @@ inline Color linear_to_gamma(const Color& c) {
 struct Random {
   virtual ~Random() = default;
   virtual double rand() = 0;
+  // A uniform addressed by a key instead of by its position in the stream.  ConstantMedium draws its free-flight
+  // sample this way (keyed by the medium's creation id), so the sample a medium gets does not depend on the order
+  // in which a traversal visits the media.  Generators without random access fall back to the stream.
+  virtual double rand_keyed(uint32_t) { return rand(); }
   double rand_interval(double mn, double mx) { return mn + (mx - mn) * rand(); }
   int64_t rand_int_interval(int64_t mn, int64_t mx) {
     int64_t range = mx - mn;
@@ -178,6 +182,14 @@ struct PhiloxRandom : Random {
     uint32_t lo = cache[(draw & 1) * 2], hi = cache[(draw & 1) * 2 + 1];
     draw++;
     uint64_t u = (((uint64_t)hi << 32) | lo) >> 11;
+    return (double)u * (1.0 / 9007199254740992.0);
+  }
+  // first uniform of block 0x80000000 | key of the current (pixel, stratum, bounce); the stream is not advanced
+  double rand_keyed(uint32_t k) override {
+    uint32_t ctr[4] = {pixel, stratum, bounce, 0x80000000u | k};
+    uint32_t out[4];
+    philox4x32_10(ctr, key, out);
+    uint64_t u = (((uint64_t)out[1] << 32) | out[0]) >> 11;
     return (double)u * (1.0 / 9007199254740992.0);
   }
 };
@@ -1138,7 +1150,7 @@ struct ConstantMedium : Node {
     if (hit1.t < 0.0) hit1.t = 0.0;
     double ray_length = ray.direction.length();
     double distance_inside_boundary = (hit2.t - hit1.t) * ray_length;
-    double hit_distance = neg_inv_density * std::log(ctx.random->rand());
+    double hit_distance = neg_inv_density * std::log(ctx.random->rand_keyed((uint32_t)id));
     if (hit_distance > distance_inside_boundary) return false;
     double t = hit1.t + hit_distance / ray_length;
     rec.pt = ray.at(t);

@@ -236,7 +236,7 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
   p.cache = !uncached && !s->flat.bvh.empty() && !(e && *e == '1');
   if (p.cache) {
     p.block = (feat & TF_MEDIA) ? 512 : 1024;
-    const bool ordered = !(feat & TF_MEDIA);  // ordered variants keep an entry distance beside every stack value
+    const bool ordered = true;  // an entry distance is kept beside every stack value
     p.cd.stack_entries = ordered ? 6 : 12;
     if (const char* es = getenv("CHIP_LDS_STACK")) { int v = atoi(es); if (v >= 2 && v <= 16) p.cd.stack_entries = (uint32_t)v; }
     uint32_t stack_bytes = p.cd.stack_entries * (ordered ? 8 : 4) * p.block;
@@ -271,21 +271,9 @@ static void launch_extend_t(const chip_scene* s, const PathPool& P, const Extend
   if (bounce == 0) launch_extend_b<F, CACHE, ORD, true>(s, P, p, n_live_upper, st, B, bounce, lit_pass);
   else launch_extend_b<F, CACHE, ORD, false>(s, P, p, n_live_upper, st, B, bounce, lit_pass);
 }
-// One bounce of traversal.  ConstantMedium scenes replay the reference's order for every ray; everything else
-// runs the ordered traversal followed by a literal pass over the rays it handed back (normally none; all of
+// One bounce of traversal: the ordered traversal followed by a literal pass over the rays it handed back (normally none; all of
 // them in a reference_order render).
 static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce) {
-  if (feat & TF_MEDIA) {
-    const ExtendPlan p = plan_extend(s, feat, false);
-    if (feat & TF_EXT) {
-      if (p.cache) launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT, true, false>(s, P, p, n_live_upper, st, B, bounce, 0);
-      else launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT, false, false>(s, P, p, n_live_upper, st, B, bounce, 0);
-    } else {
-      if (p.cache) launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, true, false>(s, P, p, n_live_upper, st, B, bounce, 0);
-      else launch_extend_t<TF_QUADS | TF_XFORM | TF_MEDIA, false, false>(s, P, p, n_live_upper, st, B, bounce, 0);
-    }
-    return;
-  }
   const ExtendPlan lit = plan_extend(s, feat, true);
   const ExtendPlan p = plan_extend(s, feat, false);
 #define CHIP_EXT(FEAT)                                                                                             \
@@ -296,7 +284,9 @@ static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat,
     case 0: CHIP_EXT(0); break;
     case TF_QUADS: CHIP_EXT(TF_QUADS); break;
     case TF_QUADS | TF_XFORM: CHIP_EXT(TF_QUADS | TF_XFORM); break;
-    default: CHIP_EXT(TF_QUADS | TF_XFORM | TF_EXT); break;
+    case TF_QUADS | TF_XFORM | TF_EXT: CHIP_EXT(TF_QUADS | TF_XFORM | TF_EXT); break;
+    case TF_QUADS | TF_XFORM | TF_MEDIA: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA); break;
+    default: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT); break;
   }
 #undef CHIP_EXT
 }

@@ -103,6 +103,16 @@ struct Rng {
     unsigned long long u = (((unsigned long long)hi << 32) | lo) >> 11;
     return (double)u * (1.0 / 9007199254740992.0);
   }
+  // A uniform addressed by a key (block 0x80000000 | key of this path and bounce) instead of by its position in
+  // the stream; the stream is not advanced.  Used for the free-flight sample of a ConstantMedium.
+  __device__ double keyed(uint32_t key) {
+    const uint32_t keep = cached_block, k0c = c[0], k1c = c[1], k2c = c[2], k3c = c[3];
+    block(0x80000000u | key);
+    const uint32_t lo = c[0], hi = c[1];
+    cached_block = keep; c[0] = k0c; c[1] = k1c; c[2] = k2c; c[3] = k3c;
+    unsigned long long u = (((unsigned long long)hi << 32) | lo) >> 11;
+    return (double)u * (1.0 / 9007199254740992.0);
+  }
   // random.rs:169-176 forms
   __device__ double interval(double mn, double mx) { return mn + (mx - mn) * next(); }
 };
@@ -239,14 +249,14 @@ __device__ inline void st_push(TravStack& s, uint32_t v, float t = 0.0f) {
     if (WITH_T) s.lds[(s.sp + s.lds_cap) << s.shift] = __float_as_uint(t);
   } else if (s.sp < s.lds_cap + CHIP_STACK_OVF) {
     if (WITH_T) { s.ovf[2 * (s.sp - s.lds_cap)] = v; s.ovf[2 * (s.sp - s.lds_cap) + 1] = __float_as_uint(t); }
-    else s.ovf[s.sp - s.lds_cap] = v;
+    else s.ovf[2 * (s.sp - s.lds_cap)] = v;  // same slots in both forms: a literal sub-traversal may run on an ordered stack
   } else { s.overflow = 1; return; }
   s.sp++;
 }
 __device__ inline uint32_t st_pop_raw(TravStack& s, int base, bool with_t) {
   if (s.sp <= base) return NREF_NONE;
   s.sp--;
-  return s.sp < s.lds_cap ? s.lds[s.sp << s.shift] : s.ovf[with_t ? 2 * (s.sp - s.lds_cap) : s.sp - s.lds_cap];
+  return s.sp < s.lds_cap ? s.lds[s.sp << s.shift] : s.ovf[2 * (s.sp - s.lds_cap)];
 }
 template <bool WITH_T>
 __device__ inline uint32_t st_pop(TravStack& s, int base, float capf = 0.0f) {
@@ -262,7 +272,7 @@ __device__ inline uint32_t st_pop(TravStack& s, int base, float capf = 0.0f) {
       v = s.ovf[2 * (s.sp - s.lds_cap)];
       t = __uint_as_float(s.ovf[2 * (s.sp - s.lds_cap) + 1]);
     } else {
-      v = s.ovf[s.sp - s.lds_cap];
+      v = s.ovf[2 * (s.sp - s.lds_cap)];
     }
     if (!WITH_T || t <= capf) return v;
   }
@@ -605,7 +615,7 @@ __device__ inline bool has_zero_component(V3 d) { return !(d.x != 0.0 && d.y != 
 // ORD selects the ordered traversal (nearer child first, f32 child-box culling, ties settled by the
 // reference's visiting order); without it the reference's own order and f64 box tests are interpreted
 // literally, which the ConstantMedium variant needs (its result depends on the interval it is handed).
-template <uint32_t F, bool YIELD, bool CACHE, bool ORD = !(F & TF_MEDIA)>
+template <uint32_t F, bool YIELD, bool CACHE, bool ORD = true>
 __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng,
                          TravStack& st, const int base, TravCounters& cnt, bool may_yield = true);
 
@@ -767,6 +777,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       const DMedium m = S.media[idx];
       const uint32_t outer_mat = r.best_mat;  // the boundary queries below overwrite it
       bool hit_medium = false;
+      if (ORD) r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);  // the boundary queries run the literal form
       double t1 = INFINITY, t2 = INFINITY;
       nref_t b1 = NREF_NONE, b2 = NREF_NONE;
       traverse_boundary<(F & TF_EXT) != 0>(S, m.boundary, r, -INFINITY, t1, b1, rng, st, cnt);
@@ -779,7 +790,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
             if (t1 < 0.0) t1 = 0.0;
             double ray_length = len(r.d);
             double inside = (t2 - t1) * ray_length;
-            double hit_distance = m.neg_inv_density * log(rng.next());
+            double hit_distance = m.neg_inv_density * log(rng.keyed((uint32_t)m.leaf_id));
             if (!(hit_distance > inside)) {
               best_t = t1 + hit_distance / ray_length;
               best = node;
@@ -789,6 +800,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
         }
       }
       r.best_mat = hit_medium ? m.mat : outer_mat;
+      if (ORD && hit_medium) r.capf = f32_above(best_t);
     }
     node = st_pop<ORD>(st, base, r.capf);
     if (YIELD && ORD && may_yield && __popcll(__ballot(1)) < CHIP_REFILL_THRESH) break;  // (the literal form is too heavy to gain from refills)
@@ -1250,7 +1262,6 @@ __host__ __device__ constexpr int extend_min_waves(uint32_t F, bool CACHE) {
 template <uint32_t F, bool CACHE, bool ORD, bool B0>
 __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CACHE)) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg, CacheDesc cd, uint32_t lit_pass) {
   const uint32_t bounce = B0 ? 0u : bounce_arg;
-  static_assert(!(ORD && (F & TF_MEDIA)), "ConstantMedium scenes are traced in the reference's order");
   // LDS layout: [4 x n_bvh uint4][4 x n_sph uint4][stack_entries x blockDim u32 values][the same again: entry distances (ORD)]
   const NodeCache C{0u, 4u * cd.n_bvh, cd.n_bvh, cd.n_sph, cd.n_bvh, cd.n_sph};
   uint32_t* lds_stack = reinterpret_cast<uint32_t*>(g_lds) + 16u * (cd.n_bvh + cd.n_sph);
@@ -1670,7 +1681,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P,
     r.wd = mk(d[3 * (size_t)i], d[3 * (size_t)i + 1], d[3 * (size_t)i + 2]);
     r.time = tm ? tm[i] : 0.0;
     r.o = r.wo; r.d = r.wd;
-    constexpr bool ORD = !(F & TF_MEDIA);
+    constexpr bool ORD = true;
     bool literal = !ORD || has_zero_component(r.wd);
     if (literal) ray_set_inv<false>(r);
     else ray_set_inv<true>(r);

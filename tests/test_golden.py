@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCENES = ["random_spheres", "final", "cornell_box", "cornell_box_smoke", "three_spheres", "perlin_spheres"]
+SCENES = ["random_spheres", "final", "cornell_box", "cornell_box_smoke", "three_spheres", "perlin_spheres", "lighted_cone_frustum", "scad_shapes"]
 KW = dict(width=32, spp=4, depth=8)
 
 
