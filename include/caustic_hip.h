@@ -98,7 +98,10 @@ enum {
    * agree except where a ray meets a bounding box exactly at the distance of a hit found earlier, which the
    * reference's `max <= min` slab rejection (axis_aligned_bounding_box.rs:207-225) turns into a miss.  Rays with a
    * zero direction component always take the literal path (their slab arithmetic forms NaNs). */
-  CHIP_RENDER_REFERENCE_ORDER = 4
+  CHIP_RENDER_REFERENCE_ORDER = 4,
+  /* 8-bit output as the wasm caller quantises it, (c * 255.0) as u8 (crates/wasm/src/lib.rs:269-276), instead of
+   * the CLI's c * 255.999 (crates/cli/src/main.rs:193-198). */
+  CHIP_RENDER_QUANTISE_255 = 8
 };
 enum { CHIP_MAT_LAMBERTIAN = 0, CHIP_MAT_METAL = 1, CHIP_MAT_DIELECTRIC = 2, CHIP_MAT_DIFFUSE_LIGHT = 3, CHIP_MAT_ISOTROPIC = 4, CHIP_MAT_EMPTY = 5 };
 /* node kinds reported by chip_dump_tree */
@@ -177,6 +180,9 @@ int chip_render_accumulate_device(chip_scene* s, const chip_render_opts* opts, f
 /* camera.rs:343-344 (+ main.rs:193-198 when out_rgb8 is set) on a device sum buffer; out_gamma /
  * out_rgb8 are device pointers, either nullable. */
 int chip_resolve_device(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, void* stream);
+/* The same with the 8-bit scale chosen by `flags` (CHIP_RENDER_QUANTISE_255 or 0). */
+int chip_resolve_device_flags(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, uint32_t flags,
+                              void* stream);
 
 /* Test hooks.  chip_trace_rays: closest hit of world over [0.001, inf) (camera.rs:264) for n host
  * rays (origin, direction: n x 3 doubles; time: n doubles or NULL = 0).  Medium free-flight draws

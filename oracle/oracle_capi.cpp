@@ -432,9 +432,10 @@ int orc_render_frame(OrcScene* s, const OrcRenderOpts* opts, double* out_sum, ui
             out_sum[idx + 2] = sum.b;
             if (out_rgb8) {
               Color g = cam.resolve(sum);
-              out_rgb8[idx] = (uint8_t)(g.r * 255.999);
-              out_rgb8[idx + 1] = (uint8_t)(g.g * 255.999);
-              out_rgb8[idx + 2] = (uint8_t)(g.b * 255.999);
+              const double q = (opts->flags & 8u) ? 255.0 : 255.999;  // wasm lib.rs:269-276 : cli main.rs:193-198
+              out_rgb8[idx] = (uint8_t)(g.r * q);
+              out_rgb8[idx + 1] = (uint8_t)(g.g * q);
+              out_rgb8[idx + 2] = (uint8_t)(g.b * q);
             }
           }
       }

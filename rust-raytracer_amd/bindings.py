@@ -90,6 +90,7 @@ assert HIT_DTYPE.itemsize == 88
 RENDER_TIME_KERNELS = 1
 RENDER_EXACT_SHADING = 2  # shade kernels keep the reference's f64 operation order (see caustic_hip.h)
 RENDER_REFERENCE_ORDER = 4  # literal replay of the reference's traversal order instead of the ordered traversal
+RENDER_QUANTISE_255 = 8  # 8-bit output scaled by 255.0 (wasm caller) instead of 255.999 (CLI)
 
 NODE_KIND_NAMES = {0: "bvh", 1: "sphere", 2: "quad", 3: "group", 4: "translate", 5: "rotate", 6: "medium", 7: "box"}
 

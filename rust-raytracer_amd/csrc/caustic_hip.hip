@@ -99,7 +99,8 @@ struct chip_scene {
       P = PathPool{};
     }
   };
-  PoolBufs pools[2];
+  static constexpr int kMaxLanes = 4;
+  PoolBufs pools[kMaxLanes];
   DevBuf<uint32_t> p_err;
   DevBuf<unsigned long long> p_stats;
   uint32_t* h_pinned = nullptr;
@@ -108,8 +109,7 @@ struct chip_scene {
     d_bvh.release(); d_tnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release();
     d_translates.release(); d_rotates.release(); d_scales.release(); d_discs.release(); d_cones.release(); d_media.release(); d_xchain.release(); d_materials.release();
     d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
-    pools[0].release();
-    pools[1].release();
+    for (int k = 0; k < kMaxLanes; k++) pools[k].release();
     p_err.release();
     p_stats.release();
     if (h_pinned) (void)hipHostFree(h_pinned);
@@ -313,13 +313,16 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
   const char* e_streams = getenv("CHIP_STREAMS");
   size_t overlap_min = (size_t)1 << 24;  // renders smaller than this are not worth splitting
   if (const char* e_min = getenv("CHIP_OVERLAP_MIN_PATHS")) overlap_min = (size_t)std::max<long long>(0, atoll(e_min));
-  const bool two = want_total >= overlap_min && pl.s_count >= 2 && !(e_streams && *e_streams == '1');
-  const size_t max_each = two ? pool_capacity_max() / 2 : pool_capacity_max();
-  const size_t want_each = two ? (size_t)pl.rw * pl.rh * ((pl.s_count + 1) / 2) : want_total;
-  const int n_lanes = two ? 2 : 1;
+  int lanes_wanted = 2;  // batches in flight (CHIP_STREAMS overrides: 1 = no overlap)
+  if (e_streams && *e_streams) lanes_wanted = std::max(1, std::min(chip_scene::kMaxLanes, atoi(e_streams)));
+  if (want_total < overlap_min) lanes_wanted = 1;
+  const int n_lanes = (int)std::min<uint32_t>((uint32_t)lanes_wanted, std::max<uint32_t>(pl.s_count, 1));
+  const size_t max_each = pool_capacity_max() / (size_t)n_lanes;
+  const size_t want_each = (size_t)pl.rw * pl.rh * ((std::max<uint32_t>(pl.s_count, 1) + n_lanes - 1) / n_lanes);
   for (int k = 0; k < n_lanes; k++)
     if (ensure_pool(s, k, want_each, max_each)) return -1;
-  const size_t cap = two ? std::min<size_t>(s->pools[0].P.cap, s->pools[1].P.cap) : s->pools[0].P.cap;
+  size_t cap = s->pools[0].P.cap;
+  for (int k = 1; k < n_lanes; k++) cap = std::min<size_t>(cap, s->pools[k].P.cap);
   if (pl.rw > cap) return fail("render rectangle is wider than the path pool");
 
   // batches: bands of rows (only when one stratum of the rectangle exceeds a pool) x groups of strata
@@ -363,9 +366,9 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
     uint32_t rb_head = 0, rb_count = 0;
     std::vector<hipEvent_t> kev;  // (trace begin, trace end = shade begin, shade end) per bounce
   };
-  Lane lanes[2];
-  const bool forked = n_lanes == 2 && batches.size() >= 2;
-  const int n_active_lanes = forked ? 2 : 1;
+  Lane lanes[chip_scene::kMaxLanes];
+  const bool forked = n_lanes >= 2 && batches.size() >= 2;
+  const int n_active_lanes = forked ? (int)std::min<size_t>((size_t)n_lanes, batches.size()) : 1;
   hipEvent_t ev0, ev1, ev_fork = nullptr;
   HIP_TRY(hipEventCreate(&ev0));
   HIP_TRY(hipEventCreate(&ev1));
@@ -925,12 +928,16 @@ int chip_render_accumulate_device(chip_scene* s, const chip_render_opts* opts, f
 }
 
 int chip_resolve_device(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, void* stream) {
+  return chip_resolve_device_flags(s, d_sum_rgb, npixels, d_out_gamma, d_out_rgb8, 0, stream);
+}
+int chip_resolve_device_flags(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, uint32_t flags,
+                              void* stream) {
   NEED_SCENE;
   if (!s->host.has_camera) return fail("scene has no camera");
   if (!d_sum_rgb) return fail("null argument");
   HIP_TRY(hipSetDevice(s->device));
   hipLaunchKernelGGL(k_resolve, dim3(grid_for(npixels * 3)), dim3(CHIP_BLOCK), 0, (hipStream_t)stream, d_sum_rgb, npixels * 3,
-                     s->host.cam.pixel_samples_scale, d_out_gamma, d_out_rgb8);
+                     s->host.cam.pixel_samples_scale, d_out_gamma, d_out_rgb8, (flags & CHIP_RENDER_QUANTISE_255) ? 255.0 : 255.999);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return 0;
@@ -955,7 +962,7 @@ int chip_render_frame(chip_scene* s, const chip_render_opts* opts, float* out_su
   if (rc == 0 && out_rgb8) {
     hipError_t e = d_rgb8.alloc(npix * 3);
     if (e == hipSuccess) {
-      rc = chip_resolve_device(s, d_sum.p, npix, nullptr, d_rgb8.p, nullptr);
+      rc = chip_resolve_device_flags(s, d_sum.p, npix, nullptr, d_rgb8.p, opts->flags, nullptr);
       if (rc == 0) e = hipMemcpy(out_rgb8, d_rgb8.p, npix * 3, hipMemcpyDeviceToHost);
     }
     if (e != hipSuccess) rc = fail(std::string("rgb8 output: ") + hipGetErrorString(e));

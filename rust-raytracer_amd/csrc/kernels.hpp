@@ -1642,9 +1642,9 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_accumulate(PathPool P, BatchDesc
 }
 
 // camera.rs:343-344 (scale, NaN -> 0 on the sum, gamma = sqrt, clamp to [0, 0.999]) and the
-// 8-bit quantisation of crates/cli/src/main.rs:193-198.
+// 8-bit quantisation of crates/cli/src/main.rs:193-198 (u8_scale 255.999) or crates/wasm/src/lib.rs:269-276 (255.0).
 __global__ void __launch_bounds__(CHIP_BLOCK) k_resolve(const float* sum_rgb, size_t n_values, double scale, float* out_gamma,
-                                                        uint8_t* out_rgb8) {
+                                                        uint8_t* out_rgb8, double u8_scale) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_values; i += (size_t)gridDim.x * blockDim.x) {
     double v = (double)sum_rgb[i];
     if (v != v) v = 0.0;
@@ -1652,7 +1652,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_resolve(const float* sum_rgb, si
     double g = v > 0.0 ? sqrt(v) : 0.0;
     g = rclamp(g, 0.0, 0.999);
     if (out_gamma) out_gamma[i] = (float)g;
-    if (out_rgb8) out_rgb8[i] = (uint8_t)(g * 255.999);
+    if (out_rgb8) out_rgb8[i] = (uint8_t)(g * u8_scale);
   }
 }
 

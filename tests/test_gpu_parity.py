@@ -322,3 +322,16 @@ def test_zero_component_rays(pkg, gpu, oracle):
     assert st_g["segments"] == st_o["segments"]
     diff = np.abs(img_g.astype(np.float64) - img_o)
     assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
+
+
+def test_rgb8_quantisation_variants(pkg, gpu, oracle):
+    """8-bit output: x 255.999 (crates/cli/src/main.rs:193-198) by default, x 255.0 (crates/wasm/src/lib.rs:269-276)
+    with the flag; both must agree with the oracle's bytes."""
+    sg, so = build_pair(pkg, gpu, oracle, "three_spheres", width=64, spp=16, depth=8)
+    for fl in (0, pkg.bindings.RENDER_QUANTISE_255):
+        _, g8, _ = sg.render_frame(seed=2, want_rgb8=True, flags=fl | pkg.bindings.RENDER_EXACT_SHADING)
+        _, o8, _ = so.render_frame(seed=2, want_rgb8=True, sum_dtype=np.float64, flags=fl)
+        assert (np.abs(g8.astype(int) - o8.astype(int)) > 1).mean() < 2e-3
+    _, a8, _ = sg.render_frame(seed=2, want_rgb8=True)
+    _, b8, _ = sg.render_frame(seed=2, want_rgb8=True, flags=pkg.bindings.RENDER_QUANTISE_255)
+    assert (a8.astype(int) - b8.astype(int)).min() >= 0 and (a8 != b8).any()
