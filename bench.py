@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # HBM bytes per launch of the traversal kernel on the default workload (1920x1080, 64-strata batches, depth 50),
 # from rocprofv3 PMC passes of this build (2 x FETCH_SIZE + WRITE_SIZE, in KB, summed over the launches of one
 # frame and divided by their number): profiles/r01/pmc_traffic_k_extend.json.  None for any other workload.
-PMC_TRAFFIC_DEFAULT_WORKLOAD = 690.8e6
+PMC_TRAFFIC_DEFAULT_WORKLOAD = 533.3e6
 
 
 def cpu_baseline(width, depth, seed):
@@ -157,7 +157,7 @@ def main():
                 "render_seed": args.seed,
             },
             "roofline": {
-                "kernel": "k_extend<0, true, true> (ordered BVH traversal: f32 child-box culling, f64 sphere tests, LDS scene cache)",
+                "kernel": "k_extend<0, true, true, *> (ordered BVH traversal: f32 child-box culling, f64 sphere tests, LDS scene cache)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
