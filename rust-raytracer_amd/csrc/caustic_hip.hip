@@ -83,13 +83,13 @@ struct chip_scene {
     DevBuf<PathHit> hit;
     DevBuf<PathMap> st;
     DevBuf<float4> sample;
-    DevBuf<uint32_t> qlive0, qlive1, qlit, counters, ovf;
+    DevBuf<uint32_t> qlit, counters, ovf;
     uint32_t counters_rows = 0;
     uint32_t* h_live = nullptr;  // pinned: live-count readback
     hipStream_t stream = nullptr;
     void release() {
       ray.release(); hit.release(); st.release(); sample.release();
-      qlive0.release(); qlive1.release(); qlit.release(); counters.release(); ovf.release();
+      qlit.release(); counters.release(); ovf.release();
       if (h_live) (void)hipHostFree(h_live);
       h_live = nullptr;
       if (stream) (void)hipStreamDestroy(stream);
@@ -133,7 +133,7 @@ static const uint32_t kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread
 
 // Largest path pool a render may use.  Every bounce of a batch is one round of kernel launches, and the
 // late bounces of a batch carry few paths, so batches are made as large as the frame allows: the
-// default of 2^28 path slots (156 B each, 42 GB) leaves that tail at a few per cent of a 1080p frame.
+// default of 2^28 path slots (260 B each, 70 GB) leaves that tail at a few per cent of a 1080p frame.
 static size_t pool_capacity_max() {
   const char* e = getenv("CHIP_POOL_PATHS");
   if (e && *e) {
@@ -142,7 +142,7 @@ static size_t pool_capacity_max() {
   }
   return (size_t)1 << 28;
 }
-static const size_t kBytesPerPathSlot = sizeof(PathRay) + sizeof(PathHit) + sizeof(PathMap) + sizeof(float4) + sizeof(uint32_t) * 3;
+static const size_t kBytesPerPathSlot = 2 * sizeof(PathRay) + sizeof(PathHit) + 2 * sizeof(PathMap) + sizeof(float4) + sizeof(uint32_t);
 
 // Makes pool `which` hold min(want_paths, max_paths, what fits in free device memory) path slots.
 static int ensure_pool(chip_scene* s, int which, size_t want_paths, size_t max_paths) {
@@ -168,13 +168,11 @@ static int ensure_pool(chip_scene* s, int which, size_t want_paths, size_t max_p
   }
   if (!pb.ready || pb.P.cap < cap) {
     pb.ray.release(); pb.hit.release(); pb.st.release(); pb.sample.release();
-    pb.qlive0.release(); pb.qlive1.release(); pb.qlit.release();
-    HIP_TRY(pb.ray.alloc(cap));
+    pb.qlit.release();
+    HIP_TRY(pb.ray.alloc(2 * cap));
     HIP_TRY(pb.hit.alloc(cap));
-    HIP_TRY(pb.st.alloc(cap));
+    HIP_TRY(pb.st.alloc(2 * cap));
     HIP_TRY(pb.sample.alloc(cap));
-    HIP_TRY(pb.qlive0.alloc(cap));
-    HIP_TRY(pb.qlive1.alloc(cap));
     HIP_TRY(pb.qlit.alloc(cap));
     pb.P.cap = (uint32_t)cap;
   }
@@ -183,8 +181,8 @@ static int ensure_pool(chip_scene* s, int which, size_t want_paths, size_t max_p
     pb.counters_rows = rows;
   }
   PathPool& P = pb.P;
-  P.ray = pb.ray.p; P.hit = pb.hit.p; P.st = pb.st.p; P.sample = pb.sample.p;
-  P.q_live[0] = pb.qlive0.p; P.q_live[1] = pb.qlive1.p; P.q_lit = pb.qlit.p;
+  P.ray[0] = pb.ray.p; P.ray[1] = pb.ray.p + P.cap; P.st[0] = pb.st.p; P.st[1] = pb.st.p + P.cap;
+  P.hit = pb.hit.p; P.sample = pb.sample.p; P.q_lit = pb.qlit.p;
   P.counters = pb.counters.p; P.errflag = s->p_err.p; P.stats = s->p_stats.p; P.ovf = pb.ovf.p;
   pb.ready = true;
   return 0;
@@ -399,6 +397,11 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
     L.active = false;
     return 0;
   };
+  static const uint32_t shade_grid_max = [] {
+    const char* e = getenv("CHIP_SHADE_GRID");
+    long v = e && *e ? atol(e) : 0;
+    return v >= 1 ? (uint32_t)v : kMaxGridBlocks;
+  }();
   // Enqueues the lane's batch from its current bounce up to the next live-count readback (or its end).
   auto advance = [&](Lane& L) -> int {
     const Batch& bt = batches[L.batch];
@@ -412,14 +415,18 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
     };
     while (L.bounce < cam.max_depth) {
       const uint32_t bounce = L.bounce;
-      const uint32_t grid = grid_for(L.live_upper);
+      const uint32_t grid = std::min(grid_for(L.live_upper), shade_grid_max);
       if (time_kernels) (void)hipEventRecord(new_event(), L.st);
       launch_extend(s, P, feat, L.live_upper, L.st, B, bounce);
       if (time_kernels) (void)hipEventRecord(new_event(), L.st);
       n_trace_launches++;
       {
         const bool ext = (feat & TF_EXT) != 0;
-#define CHIP_SHADE(FAST, LEAN, EXT) hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce)
+#define CHIP_SHADE(FAST, LEAN, EXT)                                                                                            \
+  do {                                                                                                                         \
+    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce); \
+    else hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT, false>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce); \
+  } while (0)
         if (lean) {
           if (exact_shading) CHIP_SHADE(false, true, false); else CHIP_SHADE(true, true, false);
         } else if (ext) {

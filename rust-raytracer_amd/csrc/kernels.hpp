@@ -28,14 +28,19 @@
 #define CHIP_CTR_LIT_CURSOR 9
 
 // ------------------------------------------------------------------ path pool
-// After the first bounce the live paths are a sparse subset of the slots, so every kernel reads and
-// writes path state by gathered slot index.  The state is therefore stored as one small record per
-// path and per consumer (array of structures): a lane moves its record with a few 16-byte accesses
-// inside one or two cache lines instead of touching one line per scalar field.
-struct alignas(64) PathRay {  // what traversal reads and shading rewrites
+// The live paths of a bounce are kept dense: entry i of a bounce is one small record per consumer
+// (array of structures) at index i, and shading writes the records of the paths that go on to the next
+// free indices of the other half of a ping-pong pair.  HBM moves 128-byte granules, so records gathered
+// from a sparse set of slots would waste half of every fetch (measured: 64-byte records read and written
+// at a stride of two or more reach 2.5 TB/s, dense ones 3.5 to 4.7 TB/s); the path's identity (its index
+// in the batch, which fixes its pixel, stratum and random stream) travels in the ray record instead.
+struct alignas(64) PathRay {  // what traversal reads and shading writes
   double o[3], d[3], time;
-  double pad;
+  uint32_t id;   // path index in the batch, CHIP_DEAD_ID for a reserved entry that stayed empty
+  uint32_t pad;
 };
+#define CHIP_DEAD_ID 0xFFFFFFFFu
+#define NREF_DEAD NREF(NK_NONE, 0x0FFFFFFE)  // PathHit.node of an empty entry
 struct alignas(16) PathHit {  // what traversal writes: closest hit of the current segment
   double t;
   uint32_t node;  // node reference, NREF_NONE = miss
@@ -47,13 +52,12 @@ struct alignas(16) PathMap {  // x -> clamp(a + b x, lo, hi), the composed radia
   float a[3], b[3], lo[3], hi[3];
 };
 struct PathPool {
-  PathRay* ray;     // [cap]
-  PathHit* hit;     // [cap]
-  PathMap* st;      // [cap]
-  float4* sample;   // [cap] finished sample radiance (rgb, w unused)
-  uint32_t* q_live[2];  // [cap] live path slots, ping-pong per bounce
-  uint32_t* q_lit;      // [cap] paths whose current ray the literal traversal must trace
-  uint32_t* counters;   // [max_depth+2][8]: [b][0] live entering bounce b, [b][1..6] material queue sizes, [b][7] live-queue cursor
+  PathRay* ray[2];  // [cap] each: entries of even / odd bounces
+  PathMap* st[2];   // [cap] each
+  PathHit* hit;     // [cap] by entry of the current bounce
+  float4* sample;   // [cap] by path id: finished sample radiance (rgb, w unused)
+  uint32_t* q_lit;      // [cap] entries whose ray the literal traversal must trace
+  uint32_t* counters;   // [max_depth+2][CHIP_CTR_STRIDE]: [b][0] entries of bounce b, then the cursors of the traversal kernels
   uint32_t* errflag;    // [4]: [0] traversal stack overflow
   unsigned long long* stats;  // [4]: segments, bvh visits, prim tests, spare
   uint32_t* ovf;        // [threads][2 * CHIP_STACK_OVF] traversal stack spill (value, distance pairs)
@@ -1126,30 +1130,6 @@ __device__ inline float fclampf(float v, float lo, float hi) { return v < lo ? l
 struct Affine {
   float a[3], b[3], lo[3], hi[3];
 };
-__device__ inline void affine_load(const PathPool& P, uint32_t slot, Affine& f) {
-  const float4* p = reinterpret_cast<const float4*>(P.st + slot);
-  float4 v0 = p[0], v1 = p[1], v2 = p[2];
-  f.a[0] = v0.x; f.a[1] = v0.y; f.a[2] = v0.z; f.b[0] = v0.w;
-  f.b[1] = v1.x; f.b[2] = v1.y; f.lo[0] = v1.z; f.lo[1] = v1.w;
-  f.lo[2] = v2.x; f.hi[0] = v2.y; f.hi[1] = v2.z; f.hi[2] = v2.w;
-}
-// The map of a path that has not bounced yet is the identity and is not stored.
-__device__ inline void affine_load_at(const PathPool& P, uint32_t slot, uint32_t bounce, Affine& f) {
-  float4 v0 = make_float4(0.f, 0.f, 0.f, 1.f), v1 = make_float4(1.f, 1.f, -CHIP_BIG, -CHIP_BIG), v2 = make_float4(-CHIP_BIG, CHIP_BIG, CHIP_BIG, CHIP_BIG);
-  if (bounce != 0) {
-    const float4* p = reinterpret_cast<const float4*>(P.st + slot);
-    v0 = p[0]; v1 = p[1]; v2 = p[2];
-  }
-  f.a[0] = v0.x; f.a[1] = v0.y; f.a[2] = v0.z; f.b[0] = v0.w;
-  f.b[1] = v1.x; f.b[2] = v1.y; f.lo[0] = v1.z; f.lo[1] = v1.w;
-  f.lo[2] = v2.x; f.hi[0] = v2.y; f.hi[1] = v2.z; f.hi[2] = v2.w;
-}
-__device__ inline void affine_store(const PathPool& P, uint32_t slot, const Affine& f) {
-  float4* p = reinterpret_cast<float4*>(P.st + slot);
-  p[0] = make_float4(f.a[0], f.a[1], f.a[2], f.b[0]);
-  p[1] = make_float4(f.b[1], f.b[2], f.lo[0], f.lo[1]);
-  p[2] = make_float4(f.lo[2], f.hi[0], f.hi[1], f.hi[2]);
-}
 // One bounce of camera.rs:274-304 as the per-channel map x -> clamp(e + w x, klo, khi),
 // composed on the right of the path's x -> clamp(a + b x, lo, hi).
 __device__ inline void affine_compose(Affine& f, const float e[3], const float w[3], float klo, float khi) {
@@ -1168,19 +1148,142 @@ __device__ inline void finish_path(const PathPool& P, uint32_t slot, const Affin
   P.sample[slot] = make_float4(fclampf(f.a[0] + f.b[0] * x[0], f.lo[0], f.hi[0]), fclampf(f.a[1] + f.b[1] * x[1], f.lo[1], f.hi[1]),
                                fclampf(f.a[2] + f.b[2] * x[2], f.lo[2], f.hi[2]), 0.f);
 }
-// 16-byte accesses of a path's ray record
-__device__ inline void ray_load(const PathPool& P, uint32_t slot, V3& o, V3& d, double& time) {
-  const double2* p = reinterpret_cast<const double2*>(P.ray + slot);
-  double2 a = p[0], b = p[1], c = p[2], e = p[3];
+// 16-byte accesses of a ray record
+__device__ inline void ray_load(const PathRay* rec, V3& o, V3& d, double& time, uint32_t& id) {
+  const double2* p = reinterpret_cast<const double2*>(rec);
+  double2 a = p[0], b = p[1], c = p[2];
+  const uint4 e = reinterpret_cast<const uint4*>(rec)[3];
   o = mk(a.x, a.y, b.x);
   d = mk(b.y, c.x, c.y);
-  time = e.x;
+  time = u2d(e.x, e.y);
+  id = e.z;
 }
-__device__ inline void ray_store_od(const PathPool& P, uint32_t slot, V3 o, V3 d) {
-  double2* p = reinterpret_cast<double2*>(P.ray + slot);
-  p[0] = make_double2(o.x, o.y);
-  p[1] = make_double2(o.z, d.x);
-  p[2] = make_double2(d.y, d.z);
+
+// ---- quad-cooperative record access
+// A lane that reads its own 64-byte record with four 16-byte loads touches the same cache line four times
+// in a row, and the vector L1 stalls on every access to a line whose fill is still pending.  Instead the
+// four lanes of a quad fetch one whole record per instruction (lane c takes 16-byte chunk c), one record
+// of the quad after the other, and a 4 x 4 transpose inside the quad (DPP quad permutes, no LDS) hands
+// every lane the chunks of its own record.  Stores run the same way in reverse, so a record leaves the
+// CU as one full-line write instead of four partial ones.  All 64 lanes must be active in these calls;
+// a lane without a record passes CHIP_NO_SLOT.
+#define CHIP_NO_SLOT 0xFFFFFFFFu
+template <int CTRL>
+__device__ inline uint32_t dpp_quad(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int J>
+__device__ inline uint32_t quad_bcast(uint32_t v) { return dpp_quad<J * 0x55>(v); }
+struct QuadRecord {
+  uint32_t w[4][4];  // [chunk][dword]
+};
+// Transposes lane x register inside each quad: afterwards register k of quad lane j holds what register j
+// of quad lane k held.
+__device__ inline void quad_transpose(QuadRecord& r, uint32_t lane) {
+  const bool hi2 = (lane & 2) != 0, hi1 = (lane & 1) != 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {  // exchange (lane j >= 2, register k) with (lane j - 2, register k + 2)
+      const uint32_t x = hi2 ? r.w[k][w] : r.w[k + 2][w];
+      const uint32_t y = dpp_quad<0x4E>(x);  // quad_perm [2,3,0,1]
+      r.w[k][w] = hi2 ? y : r.w[k][w];
+      r.w[k + 2][w] = hi2 ? r.w[k + 2][w] : y;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {  // exchange (odd lane j, register k) with (lane j - 1, register k + 1)
+      const uint32_t x = hi1 ? r.w[k][w] : r.w[k + 1][w];
+      const uint32_t y = dpp_quad<0xB1>(x);  // quad_perm [1,0,3,2]
+      r.w[k][w] = hi1 ? y : r.w[k][w];
+      r.w[k + 1][w] = hi1 ? r.w[k + 1][w] : y;
+    }
+  }
+}
+// Ranks the lanes of a wave that pass `take` within a shared counter, in the order in which the
+// quad-cooperative stores visit them (quad lane 0 of every quad first, then quad lane 1, ...), so that
+// each of the four store instructions writes a contiguous run of records.  All lanes must be active.
+__device__ inline uint32_t quad_order_rank(bool take, uint32_t lane, uint32_t* counter) {
+  const unsigned long long m = __ballot(take);
+  const unsigned long long g0 = 0x1111111111111111ull;
+  const uint32_t c0 = (uint32_t)__popcll(m & g0), c1 = (uint32_t)__popcll(m & (g0 << 1)), c2 = (uint32_t)__popcll(m & (g0 << 2));
+  const uint32_t j = lane & 3u;
+  const uint32_t before = j == 0 ? 0u : (j == 1 ? c0 : (j == 2 ? c0 + c1 : c0 + c1 + c2));
+  const uint32_t within = (uint32_t)__popcll(m & (g0 << j) & ((1ull << lane) - 1ull));
+  uint32_t base = 0;
+  if (m) {
+    if (lane == 0) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+  }
+  return base + before + within;
+}
+
+// Loads the first NCH 16-byte chunks of record `slot` (STRIDE bytes apart) of every lane.
+template <int STRIDE, int NCH>
+__device__ inline void quad_load(const void* base, uint32_t slot, uint32_t lane, QuadRecord& r) {
+  const uint32_t c = lane & 3;
+  uint32_t s[4] = {quad_bcast<0>(slot), quad_bcast<1>(slot), quad_bcast<2>(slot), quad_bcast<3>(slot)};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (s[j] != CHIP_NO_SLOT && (NCH == 4 || c < NCH))
+      v = *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + (size_t)s[j] * STRIDE + c * 16);
+    r.w[j][0] = v.x; r.w[j][1] = v.y; r.w[j][2] = v.z; r.w[j][3] = v.w;
+  }
+  quad_transpose(r, lane);
+}
+// Stores the first NCH chunks of the record of every lane whose slot is not CHIP_NO_SLOT.
+template <int STRIDE, int NCH>
+__device__ inline void quad_store(void* base, uint32_t slot, uint32_t lane, QuadRecord& r) {
+  const uint32_t c = lane & 3;
+  quad_transpose(r, lane);
+  uint32_t s[4] = {quad_bcast<0>(slot), quad_bcast<1>(slot), quad_bcast<2>(slot), quad_bcast<3>(slot)};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (s[j] != CHIP_NO_SLOT && (NCH == 4 || c < NCH))
+      *reinterpret_cast<uint4*>(static_cast<char*>(base) + (size_t)s[j] * STRIDE + c * 16) = make_uint4(r.w[j][0], r.w[j][1], r.w[j][2], r.w[j][3]);
+  }
+}
+__device__ inline void d2u(double v, uint32_t& lo, uint32_t& hi) {
+  lo = (uint32_t)__double2loint(v);
+  hi = (uint32_t)__double2hiint(v);
+}
+__device__ inline void ray_unpack(const QuadRecord& q, V3& o, V3& d, double& time, uint32_t& id) {
+  o = mk(u2d(q.w[0][0], q.w[0][1]), u2d(q.w[0][2], q.w[0][3]), u2d(q.w[1][0], q.w[1][1]));
+  d = mk(u2d(q.w[1][2], q.w[1][3]), u2d(q.w[2][0], q.w[2][1]), u2d(q.w[2][2], q.w[2][3]));
+  time = u2d(q.w[3][0], q.w[3][1]);
+  id = q.w[3][2];
+}
+__device__ inline void ray_pack(QuadRecord& q, V3 o, V3 d, double time, uint32_t id) {
+  d2u(o.x, q.w[0][0], q.w[0][1]); d2u(o.y, q.w[0][2], q.w[0][3]);
+  d2u(o.z, q.w[1][0], q.w[1][1]); d2u(d.x, q.w[1][2], q.w[1][3]);
+  d2u(d.y, q.w[2][0], q.w[2][1]); d2u(d.z, q.w[2][2], q.w[2][3]);
+  d2u(time, q.w[3][0], q.w[3][1]); q.w[3][2] = id; q.w[3][3] = 0;
+}
+__device__ inline void affine_unpack(const QuadRecord& q, Affine& f) {
+  f.a[0] = __uint_as_float(q.w[0][0]); f.a[1] = __uint_as_float(q.w[0][1]); f.a[2] = __uint_as_float(q.w[0][2]); f.b[0] = __uint_as_float(q.w[0][3]);
+  f.b[1] = __uint_as_float(q.w[1][0]); f.b[2] = __uint_as_float(q.w[1][1]); f.lo[0] = __uint_as_float(q.w[1][2]); f.lo[1] = __uint_as_float(q.w[1][3]);
+  f.lo[2] = __uint_as_float(q.w[2][0]); f.hi[0] = __uint_as_float(q.w[2][1]); f.hi[1] = __uint_as_float(q.w[2][2]); f.hi[2] = __uint_as_float(q.w[2][3]);
+}
+__device__ inline void affine_pack(QuadRecord& q, const Affine& f) {
+  q.w[0][0] = __float_as_uint(f.a[0]); q.w[0][1] = __float_as_uint(f.a[1]); q.w[0][2] = __float_as_uint(f.a[2]); q.w[0][3] = __float_as_uint(f.b[0]);
+  q.w[1][0] = __float_as_uint(f.b[1]); q.w[1][1] = __float_as_uint(f.b[2]); q.w[1][2] = __float_as_uint(f.lo[0]); q.w[1][3] = __float_as_uint(f.lo[1]);
+  q.w[2][0] = __float_as_uint(f.lo[2]); q.w[2][1] = __float_as_uint(f.hi[0]); q.w[2][2] = __float_as_uint(f.hi[1]); q.w[2][3] = __float_as_uint(f.hi[2]);
+  q.w[3][0] = 0; q.w[3][1] = 0; q.w[3][2] = 0; q.w[3][3] = 0;
+}
+__device__ inline void affine_identity(Affine& f) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) { f.a[c] = 0.f; f.b[c] = 1.f; f.lo[c] = -CHIP_BIG; f.hi[c] = CHIP_BIG; }
+}
+// The radiance map of every lane's entry of `bounce` (the identity before the first bounce, never stored).
+template <bool B0>
+__device__ inline void quad_load_map(const PathPool& P, uint32_t entry, uint32_t lane, uint32_t bounce, Affine& f) {
+  if (B0) {
+    affine_identity(f);
+  } else {
+    QuadRecord q;
+    quad_load<(int)sizeof(PathMap), 3>(P.st[bounce & 1], entry, lane, q);
+    affine_unpack(q, f);
+  }
 }
 
 __device__ inline void slot_to_path(const BatchDesc& B, const DCamera& cam, uint32_t slot, uint32_t& x, uint32_t& y, uint32_t& pixel,
@@ -1224,13 +1327,7 @@ __device__ inline void path_camera_ray(const DScene& S, const BatchDesc& B, uint
   rng.init(B.seed_lo, B.seed_hi, pixel, stratum, CHIP_CAMERA_BOUNCE, 0);
   camera_ray(S.cam, rng, x, y, stratum % S.cam.sqrt_spp, stratum / S.cam.sqrt_spp, o, d, time);
 }
-// The ray of the path's current segment: the camera ray at bounce 0, afterwards what shading stored.
-__device__ inline void segment_ray(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, uint32_t slot, V3& o, V3& d, double& time) {
-  if (bounce == 0) path_camera_ray(S, B, slot, o, d, time);
-  else ray_load(P, slot, o, d, time);
-}
-
-// Starts a batch: every path is live at bounce 0 (their queue is the identity and is not stored either).
+// Starts a batch: every path is live at bounce 0 (entry i is path i; nothing is stored for it yet).
 __global__ void k_begin_batch(PathPool P, BatchDesc B) {
   if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[0] = B.n_paths;
 }
@@ -1280,7 +1377,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
     }
     __syncthreads();
   }
-  const uint32_t* q_in = lit_pass ? P.q_lit : P.q_live[bounce & 1];
+  const PathRay* ray_in = P.ray[bounce & 1];
   uint32_t* cursor = lit_pass ? &ctr[CHIP_CTR_LIT_CURSOR] : &ctr[CHIP_CTR_CURSOR];
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = __lane_id();
@@ -1295,7 +1392,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
   TravCounters cnt{0, 0};
   uint32_t nseg = 0;
   bool has = false;  // this lane holds a ray (traversing or finished)
-  uint32_t slot = 0;
+  uint32_t entry = 0;
   TravRay r;
   r.wo = r.wd = r.o = r.d = r.inv = mk(0, 0, 0);
   r.time = 0;
@@ -1315,14 +1412,14 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
     if (has && node == NREF_NONE) {
       if (ORD && st.redo) {  // handed back by the ordered traversal: goes to the literal queue instead
         st.redo = 0;
-        P.q_lit[atomicAdd(&ctr[CHIP_CTR_LIT], 1u)] = slot;
+        P.q_lit[atomicAdd(&ctr[CHIP_CTR_LIT], 1u)] = entry;
       } else {
         nseg++;
         PathHit ph;
         ph.t = best_t;
         ph.node = best;
         ph.info = (r.best_mat & 0xFFFFFFu) | ((F & TF_MEDIA) ? (rng.draw << 24) : 0u);
-        *reinterpret_cast<uint4*>(P.hit + slot) = *reinterpret_cast<const uint4*>(&ph);
+        *reinterpret_cast<uint4*>(P.hit + entry) = *reinterpret_cast<const uint4*>(&ph);
       }
       has = false;
     }
@@ -1342,10 +1439,13 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
         const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
         const uint32_t avail = w_end - w_next;
         if (!has && rank < avail) {
-          slot = (B0 && !lit_pass) ? w_next + rank : q_in[w_next + rank];
-          if (B0) path_camera_ray(S, B, slot, r.wo, r.wd, r.time);
-          else ray_load(P, slot, r.wo, r.wd, r.time);
-          const bool to_literal = ORD && (B.reference_order || has_zero_component(r.wd));
+          entry = lit_pass ? P.q_lit[w_next + rank] : w_next + rank;
+          uint32_t id = entry;  // at bounce 0 entry i is path i
+          if (B0) path_camera_ray(S, B, entry, r.wo, r.wd, r.time);
+          else ray_load(ray_in + entry, r.wo, r.wd, r.time, id);
+          const bool dead = !B0 && id == CHIP_DEAD_ID;  // reserved by the last shading pass but left empty
+          if (dead) *reinterpret_cast<uint4*>(P.hit + entry) = make_uint4(0u, 0u, NREF_DEAD, 0u);
+          const bool to_literal = !dead && ORD && (B.reference_order || has_zero_component(r.wd));
           if (ORD) {  // the literal queue takes these rays (appended with one atomic per wave)
             const unsigned long long ml = __ballot(to_literal);
             if (ml) {
@@ -1353,16 +1453,16 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
               uint32_t lbase = 0;
               if (lane == leader) lbase = atomicAdd(&ctr[CHIP_CTR_LIT], (uint32_t)__popcll(ml));
               lbase = __shfl(lbase, leader);
-              if (to_literal) P.q_lit[lbase + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull))] = slot;
+              if (to_literal) P.q_lit[lbase + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull))] = entry;
             }
           }
-          if (!to_literal) {
+          if (!to_literal && !dead) {
             r.o = r.wo; r.d = r.wd;
             ray_set_inv<ORD>(r);
             r.capf = INFINITY;
             if (F & TF_MEDIA) {
               uint32_t x, y, pixel, stratum;
-              slot_to_path(B, S.cam, slot, x, y, pixel, stratum);
+              slot_to_path(B, S.cam, id, x, y, pixel, stratum);
               rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, 0);
             }
             best_t = INFINITY;
@@ -1396,16 +1496,16 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
 
 // One hit of one path: Material::emitted / scatter / scattering_pdf of material kind KIND plus the PDF
 // branch of camera.rs:278-305.  The segment's ray (ro, rd, rtime) and closest hit (ph) come from the
-// caller; the path's radiance map is updated, the next ray stored and true returned if the path goes on,
-// otherwise the path's sample is written.
+// caller.  Returns true with the next ray and the bounce's map x -> clamp(xw x, klo, khi) if the material
+// scattered, false with the radiance xw that ends the path otherwise; the caller composes either with the
+// path's radiance map, which therefore need not occupy registers here.
 // LEAN is the variant for scenes made only of spheres with solid-colour textures and no lights (no
 // transforms, quads, media, image / noise / checker textures or light sampling to carry in registers).
 template <uint32_t KIND, bool FAST, bool LEAN, bool EXT>
-__device__ inline bool shade_hit(const DScene& S, const PathPool& P, const BatchDesc& B, uint32_t bounce, bool last_bounce, uint32_t slot,
-                                 const PathHit& ph, V3 ro, V3 rd, double rtime) {
+__device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t bounce, uint32_t slot, const PathHit& ph, V3 ro, V3 rd,
+                                 double rtime, float (&xw)[3], float& klo_out, float& khi_out, V3& next_o, V3& next_d) {
   bool cont = false;
-  Affine f;
-  affine_load_at(P, slot, bounce, f);
+  xw[0] = 0.f; xw[1] = 0.f; xw[2] = 0.f;
   // HitRecord of the segment's closest hit (object/mod.rs:31-51), rebuilt from (ray, t, node)
   const nref_t leaf = ph.node;
   const DMaterial& M = S.materials[MATK_ID(ph.info)];
@@ -1416,15 +1516,12 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
   const V3 pt = hrec.pt;
   if (KIND == MK_DIFFUSE_LIGHT) {
     // diffuse_light.rs:28-43: no scatter; emits on the front face only
-    float x[3] = {0.f, 0.f, 0.f};
     if (front) {
       V3 e = LEAN ? ld3(M.p) : tex_value(S, M.tex, hrec.u, hrec.v, pt);
-      x[0] = (float)e.x; x[1] = (float)e.y; x[2] = (float)e.z;
+      xw[0] = (float)e.x; xw[1] = (float)e.y; xw[2] = (float)e.z;
     }
-    finish_path(P, slot, f, x);
   } else if (KIND == MK_EMPTY) {
-    float x[3] = {0.f, 0.f, 0.f};  // empty.rs:18-27 + default emitted
-    finish_path(P, slot, f, x);
+    // empty.rs:18-27 + default emitted: zero radiance
   } else {
     const V3 nrm = hrec.n;
     uint32_t x_, y_, pixel, stratum;
@@ -1433,7 +1530,7 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
     rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, PATHHIT_DRAW(ph.info));
     V3 ndir;
     bool terminal = false;
-    float e[3] = {0.f, 0.f, 0.f}, w[3];
+    float w[3] = {0.f, 0.f, 0.f};
     float klo = -CHIP_BIG, khi = CHIP_BIG;
     if (KIND == MK_METAL) {  // metal.rs:20-28
       V3 reflected = reflect(rd, nrm);
@@ -1525,59 +1622,54 @@ __device__ inline bool shade_hit(const DScene& S, const PathPool& P, const Batch
       }
       }
     }
-    if (terminal) {
-      float x[3] = {0.f, 0.f, 0.f};
-      finish_path(P, slot, f, x);
-    } else {
-      affine_compose(f, e, w, klo, khi);
-      if (last_bounce) {
-        float x[3] = {0.f, 0.f, 0.f};  // camera.rs:259-261
-        finish_path(P, slot, f, x);
-      } else {
-        affine_store(P, slot, f);
-        ray_store_od(P, slot, pt, ndir);  // the time of the path's rays never changes (camera.rs:287):
-        if (bounce == 0) reinterpret_cast<double2*>(P.ray + slot)[3] = make_double2(rtime, 0.0);  // stored once
-        cont = true;
-      }
+    if (!terminal) {  // (a terminal path returns the emission, zero for these materials: camera.rs:291-293)
+      xw[0] = w[0]; xw[1] = w[1]; xw[2] = w[2];
+      klo_out = klo; khi_out = khi;
+      next_o = pt;  // the caller stores the map and the next ray (its time never changes, camera.rs:287)
+      next_d = ndir;
+      cont = true;
     }
   }
   return cont;
 }
 
-// Material-binned shading of one bounce.  A block takes a tile of the live queue, bins the tile's entries by
-// the material kind of their hit in LDS (a counting sort, misses last), and shades the tile kind after kind,
-// so a wave runs one material's code except where two kinds meet.  Misses take the background
-// (camera.rs:264-266); surviving paths are compacted in LDS and appended to the next bounce's live queue
-// with one global atomic per tile.  Binning per tile instead of through global per-material queues saves
-// a pass over the hit records and the queue traffic.
+// Material-binned shading of one bounce.  A block takes a tile of the bounce's entries, bins them by the
+// material kind of their hit in LDS (a counting sort; misses and empty entries last), and shades the tile
+// kind after kind, so a wave runs one material's code except where two kinds meet.  Misses take the
+// background (camera.rs:264-266).  The tile reserves room for every entry that can scatter in the next
+// bounce's arrays with one global atomic, the paths that go on write their new ray and radiance map
+// there, and the few reserved entries left over (paths ended by camera.rs:291-293) are marked empty.
 #define CHIP_SHADE_TILE 1024
-template <bool FAST, bool LEAN, bool EXT>
-__global__ void __launch_bounds__(CHIP_BLOCK) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce) {
-  const uint32_t* q_in = P.q_live[bounce & 1];
-  uint32_t* q_out = P.q_live[(bounce + 1) & 1];
+// B0: the instantiation for bounce 0, whose entries are the batch's paths in order with their camera rays
+// recomputed and the identity as radiance map; kept apart so that neither variant pays registers for the other.
+template <bool FAST, bool LEAN, bool EXT, bool B0>
+__global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg) {
+  const uint32_t bounce = B0 ? 0u : bounce_arg;
+  const PathRay* ray_in = P.ray[bounce & 1];
+  PathRay* ray_out = P.ray[(bounce + 1) & 1];
+  PathMap* st_out = P.st[(bounce + 1) & 1];
   uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
   uint32_t* ctr_next = P.counters + (size_t)(bounce + 1) * CHIP_CTR_STRIDE;
   const uint32_t n_live = ctr[0];
   const bool last_bounce = bounce + 1 >= S.cam.max_depth;
-  constexpr uint32_t NB = MK_COUNT + 1;        // material kinds + misses
-  __shared__ uint32_t s_a[CHIP_SHADE_TILE];    // queue order while sorting, then the tile's surviving paths
-  __shared__ uint32_t s_sorted[CHIP_SHADE_TILE];
+  constexpr uint32_t NB = MK_COUNT + 2;        // material kinds, misses, empty entries
+  __shared__ uint16_t s_order[CHIP_SHADE_TILE];  // tile-local entry numbers, sorted by bin
   __shared__ uint16_t s_rank[CHIP_SHADE_TILE];
   __shared__ uint8_t s_kind[CHIP_SHADE_TILE];
-  __shared__ uint32_t s_cnt[NB], s_off[NB + 1], s_live, s_base;
+  __shared__ uint32_t s_cnt[NB], s_off[NB + 1], s_live, s_base, s_reserved;
   // entries per tile: up to CHIP_SHADE_TILE, but small enough that a short queue still spreads over the grid
   uint32_t tile = (n_live / gridDim.x) & ~(uint32_t)(CHIP_BLOCK - 1);
   tile = tile < CHIP_BLOCK ? CHIP_BLOCK : (tile > CHIP_SHADE_TILE ? CHIP_SHADE_TILE : tile);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t lane_entry = 16u * (lane & 3u) + (lane >> 2);
   for (uint32_t tile0 = blockIdx.x * tile; tile0 < n_live; tile0 += gridDim.x * tile) {
     if (threadIdx.x < NB) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_live = 0;
     __syncthreads();
     const uint32_t tile_n = min(tile, n_live - tile0);
     for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
-      const uint32_t slot = bounce == 0 ? tile0 + k : q_in[tile0 + k];
-      const uint2 hw = *reinterpret_cast<const uint2*>(&P.hit[slot].node);
-      const uint32_t kind = hw.x == NREF_NONE ? MK_COUNT : MATK_KIND(hw.y);
-      s_a[k] = slot;
+      const uint2 hw = *reinterpret_cast<const uint2*>(&P.hit[tile0 + k].node);
+      const uint32_t kind = hw.x == NREF_NONE ? MK_COUNT : (hw.x == NREF_DEAD ? MK_COUNT + 1 : MATK_KIND(hw.y));
       s_kind[k] = (uint8_t)kind;
       s_rank[k] = (uint16_t)atomicAdd(&s_cnt[kind], 1u);
     }
@@ -1586,21 +1678,62 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade_tiles(DScene S, PathPool P
       uint32_t acc = 0;
       for (uint32_t b = 0; b < NB; b++) { s_off[b] = acc; acc += s_cnt[b]; }
       s_off[NB] = acc;
+      // room for every entry whose material can scatter (camera.rs:278)
+      const uint32_t reserve = last_bounce ? 0u : s_cnt[MK_LAMBERTIAN] + s_cnt[MK_METAL] + s_cnt[MK_DIELECTRIC] + s_cnt[MK_ISOTROPIC];
+      s_reserved = reserve;
+      s_base = reserve ? atomicAdd(&ctr_next[0], reserve) : 0u;
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) s_sorted[s_off[s_kind[k]] + s_rank[k]] = s_a[k];
+    for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) s_order[s_off[s_kind[k]] + s_rank[k]] = (uint16_t)k;
     __syncthreads();
-    // one loop per bin, so that each material's code is register-allocated on its own
+    // One loop per bin, so that each material's code is register-allocated on its own.  A wave takes 64
+    // consecutive entries of the bin per trip; lane 4q + m shades entry 16m + q of them, which makes load j
+    // of the quad-cooperative accesses cover entries 16j .. 16j + 15.  The trip count is wave-uniform.
 #define CHIP_SHADE_BIN(KIND)                                                                                     \
-  _Pragma("clang loop unroll(disable)")                                                                          \
-  for (uint32_t k = s_off[KIND] + threadIdx.x; k < s_off[KIND + 1]; k += CHIP_BLOCK) {                           \
-    const uint32_t slot = s_sorted[k];                                                                           \
-    PathHit ph;                                                                                                  \
-    *reinterpret_cast<uint4*>(&ph) = *reinterpret_cast<const uint4*>(P.hit + slot);                              \
-    V3 ro, rd;                                                                                                   \
-    double rtime;                                                                                                \
-    segment_ray(S, P, B, bounce, slot, ro, rd, rtime);                                                           \
-    if (shade_hit<KIND, FAST, LEAN, EXT>(S, P, B, bounce, last_bounce, slot, ph, ro, rd, rtime)) s_a[atomicAdd(&s_live, 1u)] = slot; \
+  {                                                                                                              \
+    const uint32_t bin_end = __builtin_amdgcn_readfirstlane(s_off[KIND + 1]);                                    \
+    _Pragma("clang loop unroll(disable)")                                                                        \
+    for (uint32_t k0 = __builtin_amdgcn_readfirstlane(s_off[KIND] + (threadIdx.x & ~63u)); k0 < bin_end; k0 += CHIP_BLOCK) { \
+      const uint32_t k = k0 + lane_entry;                                                                        \
+      const bool valid = k < bin_end;                                                                            \
+      const uint32_t entry = valid ? tile0 + s_order[k] : CHIP_NO_SLOT;                                          \
+      PathHit ph;                                                                                                \
+      ph.t = 0.0; ph.node = NREF_NONE; ph.info = 0;                                                              \
+      if (valid) *reinterpret_cast<uint4*>(&ph) = *reinterpret_cast<const uint4*>(P.hit + entry);                \
+      V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0), no = mk(0, 0, 0), nd = mk(0, 0, 0);                                  \
+      double rtime = 0.0;                                                                                        \
+      uint32_t id = entry;                                                                                       \
+      if (B0) {                                                                                                  \
+        if (valid) path_camera_ray(S, B, entry, ro, rd, rtime);                                                  \
+      } else {                                                                                                   \
+        QuadRecord q;                                                                                            \
+        quad_load<(int)sizeof(PathRay), 4>(ray_in, entry, lane, q);                                              \
+        ray_unpack(q, ro, rd, rtime, id);                                                                        \
+      }                                                                                                          \
+      float xw[3] = {0.f, 0.f, 0.f}, klo = 0.f, khi = 0.f;                                                       \
+      bool cont = false;                                                                                         \
+      if (valid) cont = shade_hit<KIND, FAST, LEAN, EXT>(S, B, bounce, id, ph, ro, rd, rtime, xw, klo, khi, no, nd); \
+      Affine f;  /* loaded after the material code, which is where the registers are scarce */                  \
+      quad_load_map<B0>(P, entry, lane, bounce, f);                                                                  \
+      if (valid) {                                                                                               \
+        if (cont) {                                                                                              \
+          const float e0[3] = {0.f, 0.f, 0.f};                                                                   \
+          affine_compose(f, e0, xw, klo, khi);                                                                   \
+          xw[0] = 0.f; xw[1] = 0.f; xw[2] = 0.f;                                                                 \
+          cont = !last_bounce;  /* camera.rs:259-261 */                                                          \
+        }                                                                                                        \
+        if (!cont) finish_path(P, id, f, xw);                                                                    \
+      }                                                                                                          \
+      const uint32_t out_rank = quad_order_rank(cont, lane, &s_live);  /* every lane takes part */               \
+      const uint32_t out = cont ? s_base + out_rank : CHIP_NO_SLOT;                                              \
+      {                                                                                                          \
+        QuadRecord q;                                                                                            \
+        ray_pack(q, no, nd, rtime, id);                                                                          \
+        quad_store<(int)sizeof(PathRay), 4>(ray_out, out, lane, q);                                              \
+        affine_pack(q, f);                                                                                       \
+        quad_store<(int)sizeof(PathMap), 3>(st_out, out, lane, q);                                               \
+      }                                                                                                          \
+    }                                                                                                            \
   }
     CHIP_SHADE_BIN(MK_LAMBERTIAN)
     CHIP_SHADE_BIN(MK_METAL)
@@ -1609,17 +1742,24 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_shade_tiles(DScene S, PathPool P
     CHIP_SHADE_BIN(MK_ISOTROPIC)
     CHIP_SHADE_BIN(MK_EMPTY)
 #undef CHIP_SHADE_BIN
-    for (uint32_t k = s_off[MK_COUNT] + threadIdx.x; k < s_off[MK_COUNT + 1]; k += CHIP_BLOCK) {  // misses, camera.rs:264-266
-      const uint32_t slot = s_sorted[k];
-      Affine f;
-      affine_load_at(P, slot, bounce, f);
-      float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
-      finish_path(P, slot, f, bg);
+    {  // misses, camera.rs:264-266
+      const uint32_t bin_end = __builtin_amdgcn_readfirstlane(s_off[MK_COUNT + 1]);
+      for (uint32_t k0 = __builtin_amdgcn_readfirstlane(s_off[MK_COUNT] + (threadIdx.x & ~63u)); k0 < bin_end; k0 += CHIP_BLOCK) {
+        const uint32_t k = k0 + lane_entry;
+        const bool valid = k < bin_end;
+        const uint32_t entry = valid ? tile0 + s_order[k] : CHIP_NO_SLOT;
+        uint32_t id = entry;
+        if (valid && !B0) id = reinterpret_cast<const uint4*>(ray_in + entry)[3].z;
+        Affine f;
+        quad_load_map<B0>(P, entry, lane, bounce, f);
+        float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
+        if (valid) finish_path(P, id, f, bg);
+      }
     }
     __syncthreads();
-    if (threadIdx.x == 0) s_base = s_live ? atomicAdd(&ctr_next[0], s_live) : 0u;
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < s_live; k += CHIP_BLOCK) q_out[s_base + k] = s_a[k];
+    // reserved entries that no path took
+    for (uint32_t k = s_live + threadIdx.x; k < s_reserved; k += CHIP_BLOCK)
+      reinterpret_cast<uint4*>(ray_out + s_base + k)[3] = make_uint4(0u, 0u, CHIP_DEAD_ID, 0u);
     __syncthreads();
   }
 }
