@@ -188,6 +188,14 @@ static int ensure_pool(chip_scene* s, int which, size_t want_paths, size_t max_p
   return 0;
 }
 
+// ceil(2^64 / d) for magic_div (0 for d = 1, where the quotient is the dividend)
+static void set_magic(uint32_t out[2], uint32_t d) {
+  unsigned long long c = 0;
+  if (d > 1) c = ~0ull / d + 1;  // floor((2^64 - 1) / d) + 1 = ceil(2^64 / d) for every d that does not divide 2^64 ...
+  if (d > 1 && (d & (d - 1)) == 0) c = (1ull << 63) / (d >> 1);  // ... and for the powers of two exactly 2^64 / d
+  out[0] = (uint32_t)c;
+  out[1] = (uint32_t)(c >> 32);
+}
 static uint32_t grid_for(size_t n) {
   size_t b = (n + CHIP_BLOCK - 1) / CHIP_BLOCK;
   if (b < 1) b = 1;
@@ -340,6 +348,8 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       BatchDesc& B = bt.B;
       B.rect_x0 = pl.xmin; B.rect_y0 = pl.ymin + by; B.rect_w = pl.rw; B.rect_h = bh;
       B.npix = npix;
+      set_magic(B.npix_magic, npix);
+      set_magic(B.rect_w_magic, pl.rw);
       B.n_strata = std::min(spb, pl.s_count - sb0);
       B.stratum_first = pl.s_first + sb0 * pl.s_stride;
       B.stratum_stride = pl.s_stride;

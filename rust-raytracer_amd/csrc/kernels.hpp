@@ -70,6 +70,7 @@ struct BatchDesc {
   uint32_t n_strata;                          // strata in this batch
   uint32_t stratum_first, stratum_stride;     // global stratum of batch-local sb: first + sb*stride
   uint32_t n_paths;                           // npix * n_strata
+  uint32_t npix_magic[2], rect_w_magic[2];    // ceil(2^64 / divisor), low and high word (0, 0 for a divisor of 1)
   uint32_t seed_lo, seed_hi;
   uint32_t reference_order;                   // trace every ray in the reference's own visiting order
 };
@@ -89,8 +90,9 @@ struct Rng {
     uint32_t c0 = pixel, c1 = stratum, c2 = bounce, c3 = blk, a = k0, b = k1;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
-      uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-      uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of separate high and low halves
+      const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+      const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
       uint32_t n0 = hi1 ^ c1 ^ a, n2 = hi0 ^ c3 ^ b;
       c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
       a += 0x9E3779B9u;
@@ -1161,13 +1163,15 @@ __device__ inline void ray_load(const PathRay* rec, V3& o, V3& d, double& time, 
 
 // ---- quad-cooperative record access
 // A lane that reads its own 64-byte record with four 16-byte loads touches the same cache line four times
-// in a row, and the vector L1 stalls on every access to a line whose fill is still pending.  Instead the
-// four lanes of a quad fetch one whole record per instruction (lane c takes 16-byte chunk c), one record
-// of the quad after the other, and a 4 x 4 transpose inside the quad (DPP quad permutes, no LDS) hands
-// every lane the chunks of its own record.  Stores run the same way in reverse, so a record leaves the
-// CU as one full-line write instead of four partial ones.  All 64 lanes must be active in these calls;
-// a lane without a record passes CHIP_NO_SLOT.
+// in a row, and its stores leave the CU as four partial-line writes.  Instead the four lanes of a quad
+// move one whole record per instruction (lane c takes 16-byte chunk c), one record of the quad after the
+// other, and the chunks change hands through a per-wave LDS staging buffer, so that every lane ends up
+// with (or starts from) the chunks of its own record.  All 64 lanes must be active in these calls; a
+// lane without a record passes CHIP_NO_SLOT.
+// Lane 4q + m owns wave entry 16m + q, so that access j of a quad (the record of quad lane j) covers wave
+// entries 16j .. 16j + 15 across the wave: consecutive entries, consecutive records.
 #define CHIP_NO_SLOT 0xFFFFFFFFu
+#define CHIP_XPOSE_U4 260  // uint4 per wave: 64 records of 4 chunks plus one chunk of padding per 16 records
 template <int CTRL>
 __device__ inline uint32_t dpp_quad(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
@@ -1177,28 +1181,9 @@ __device__ inline uint32_t quad_bcast(uint32_t v) { return dpp_quad<J * 0x55>(v)
 struct QuadRecord {
   uint32_t w[4][4];  // [chunk][dword]
 };
-// Transposes lane x register inside each quad: afterwards register k of quad lane j holds what register j
-// of quad lane k held.
-__device__ inline void quad_transpose(QuadRecord& r, uint32_t lane) {
-  const bool hi2 = (lane & 2) != 0, hi1 = (lane & 1) != 0;
-#pragma unroll
-  for (int w = 0; w < 4; w++) {
-#pragma unroll
-    for (int k = 0; k < 2; k++) {  // exchange (lane j >= 2, register k) with (lane j - 2, register k + 2)
-      const uint32_t x = hi2 ? r.w[k][w] : r.w[k + 2][w];
-      const uint32_t y = dpp_quad<0x4E>(x);  // quad_perm [2,3,0,1]
-      r.w[k][w] = hi2 ? y : r.w[k][w];
-      r.w[k + 2][w] = hi2 ? r.w[k + 2][w] : y;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k += 2) {  // exchange (odd lane j, register k) with (lane j - 1, register k + 1)
-      const uint32_t x = hi1 ? r.w[k][w] : r.w[k + 1][w];
-      const uint32_t y = dpp_quad<0xB1>(x);  // quad_perm [1,0,3,2]
-      r.w[k][w] = hi1 ? y : r.w[k][w];
-      r.w[k + 1][w] = hi1 ? r.w[k + 1][w] : y;
-    }
-  }
-}
+// Staging position (in uint4) of chunk 0 of wave entry e: the padding makes both the quad-wise and the
+// lane-wise accesses conflict-free (16 consecutive lanes always cover the 16 bank groups).
+__device__ inline uint32_t xpose_at(uint32_t e) { return 4u * e + (e >> 4); }
 // Ranks the lanes of a wave that pass `take` within a shared counter, in the order in which the
 // quad-cooperative stores visit them (quad lane 0 of every quad first, then quad lane 1, ...), so that
 // each of the four store instructions writes a contiguous run of records.  All lanes must be active.
@@ -1219,29 +1204,42 @@ __device__ inline uint32_t quad_order_rank(bool take, uint32_t lane, uint32_t* c
 
 // Loads the first NCH 16-byte chunks of record `slot` (STRIDE bytes apart) of every lane.
 template <int STRIDE, int NCH>
-__device__ inline void quad_load(const void* base, uint32_t slot, uint32_t lane, QuadRecord& r) {
-  const uint32_t c = lane & 3;
+__device__ inline void quad_load(const void* base, uint32_t slot, uint32_t lane, uint4* stage, QuadRecord& r) {
+  const uint32_t c = lane & 3, q = lane >> 2;
   uint32_t s[4] = {quad_bcast<0>(slot), quad_bcast<1>(slot), quad_bcast<2>(slot), quad_bcast<3>(slot)};
+  uint4 v[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    uint4 v = make_uint4(0, 0, 0, 0);
+    v[j] = make_uint4(0, 0, 0, 0);
     if (s[j] != CHIP_NO_SLOT && (NCH == 4 || c < NCH))
-      v = *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + (size_t)s[j] * STRIDE + c * 16);
-    r.w[j][0] = v.x; r.w[j][1] = v.y; r.w[j][2] = v.z; r.w[j][3] = v.w;
+      v[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + (size_t)s[j] * STRIDE + c * 16);
   }
-  quad_transpose(r, lane);
+#pragma unroll
+  for (int j = 0; j < 4; j++) stage[xpose_at(16u * j + q) + c] = v[j];
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t own = xpose_at(16u * c + q);
+#pragma unroll
+  for (int k = 0; k < NCH; k++) {
+    const uint4 t = stage[own + k];
+    r.w[k][0] = t.x; r.w[k][1] = t.y; r.w[k][2] = t.z; r.w[k][3] = t.w;
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 // Stores the first NCH chunks of the record of every lane whose slot is not CHIP_NO_SLOT.
 template <int STRIDE, int NCH>
-__device__ inline void quad_store(void* base, uint32_t slot, uint32_t lane, QuadRecord& r) {
-  const uint32_t c = lane & 3;
-  quad_transpose(r, lane);
+__device__ inline void quad_store(void* base, uint32_t slot, uint32_t lane, uint4* stage, const QuadRecord& r) {
+  const uint32_t c = lane & 3, q = lane >> 2;
+  const uint32_t own = xpose_at(16u * c + q);
+#pragma unroll
+  for (int k = 0; k < NCH; k++) stage[own + k] = make_uint4(r.w[k][0], r.w[k][1], r.w[k][2], r.w[k][3]);
+  __builtin_amdgcn_wave_barrier();
   uint32_t s[4] = {quad_bcast<0>(slot), quad_bcast<1>(slot), quad_bcast<2>(slot), quad_bcast<3>(slot)};
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     if (s[j] != CHIP_NO_SLOT && (NCH == 4 || c < NCH))
-      *reinterpret_cast<uint4*>(static_cast<char*>(base) + (size_t)s[j] * STRIDE + c * 16) = make_uint4(r.w[j][0], r.w[j][1], r.w[j][2], r.w[j][3]);
+      *reinterpret_cast<uint4*>(static_cast<char*>(base) + (size_t)s[j] * STRIDE + c * 16) = stage[xpose_at(16u * j + q) + c];
   }
+  __builtin_amdgcn_wave_barrier();
 }
 __device__ inline void d2u(double v, uint32_t& lo, uint32_t& hi) {
   lo = (uint32_t)__double2loint(v);
@@ -1276,21 +1274,29 @@ __device__ inline void affine_identity(Affine& f) {
 }
 // The radiance map of every lane's entry of `bounce` (the identity before the first bounce, never stored).
 template <bool B0>
-__device__ inline void quad_load_map(const PathPool& P, uint32_t entry, uint32_t lane, uint32_t bounce, Affine& f) {
+__device__ inline void quad_load_map(const PathPool& P, uint32_t entry, uint32_t lane, uint32_t bounce, uint4* stage, Affine& f) {
   if (B0) {
     affine_identity(f);
   } else {
     QuadRecord q;
-    quad_load<(int)sizeof(PathMap), 3>(P.st[bounce & 1], entry, lane, q);
+    quad_load<(int)sizeof(PathMap), 3>(P.st[bounce & 1], entry, lane, stage, q);
     affine_unpack(q, f);
   }
 }
 
+// n / d for a batch-constant divisor d through its precomputed reciprocal c = ceil(2^64 / d): the high 64
+// bits of c * n are exactly floor(n / d) for every 32-bit n (c = 0 stands for d = 1).
+__host__ __device__ inline uint32_t magic_div(uint32_t n, const uint32_t c[2]) {
+  if ((c[0] | c[1]) == 0u) return n;
+  const unsigned long long lo = (unsigned long long)c[0] * n, hi = (unsigned long long)c[1] * n;
+  return (uint32_t)((hi + (lo >> 32)) >> 32);
+}
 __device__ inline void slot_to_path(const BatchDesc& B, const DCamera& cam, uint32_t slot, uint32_t& x, uint32_t& y, uint32_t& pixel,
                                     uint32_t& stratum) {
-  uint32_t sb = slot / B.npix, p = slot - sb * B.npix;
-  y = B.rect_y0 + p / B.rect_w;
-  x = B.rect_x0 + p % B.rect_w;
+  const uint32_t sb = magic_div(slot, B.npix_magic), p = slot - sb * B.npix;
+  const uint32_t row = magic_div(p, B.rect_w_magic);
+  y = B.rect_y0 + row;
+  x = B.rect_x0 + (p - row * B.rect_w);
   pixel = y * cam.image_width + x;
   stratum = B.stratum_first + sb * B.stratum_stride;
 }
@@ -1657,6 +1663,8 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_ti
   __shared__ uint16_t s_rank[CHIP_SHADE_TILE];
   __shared__ uint8_t s_kind[CHIP_SHADE_TILE];
   __shared__ uint32_t s_cnt[NB], s_off[NB + 1], s_live, s_base, s_reserved;
+  __shared__ uint4 s_stage[CHIP_BLOCK / 64][CHIP_XPOSE_U4];
+  uint4* stage = s_stage[threadIdx.x >> 6];
   // entries per tile: up to CHIP_SHADE_TILE, but small enough that a short queue still spreads over the grid
   uint32_t tile = (n_live / gridDim.x) & ~(uint32_t)(CHIP_BLOCK - 1);
   tile = tile < CHIP_BLOCK ? CHIP_BLOCK : (tile > CHIP_SHADE_TILE ? CHIP_SHADE_TILE : tile);
@@ -1707,14 +1715,14 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_ti
         if (valid) path_camera_ray(S, B, entry, ro, rd, rtime);                                                  \
       } else {                                                                                                   \
         QuadRecord q;                                                                                            \
-        quad_load<(int)sizeof(PathRay), 4>(ray_in, entry, lane, q);                                              \
+        quad_load<(int)sizeof(PathRay), 4>(ray_in, entry, lane, stage, q);                                            \
         ray_unpack(q, ro, rd, rtime, id);                                                                        \
       }                                                                                                          \
       float xw[3] = {0.f, 0.f, 0.f}, klo = 0.f, khi = 0.f;                                                       \
       bool cont = false;                                                                                         \
       if (valid) cont = shade_hit<KIND, FAST, LEAN, EXT>(S, B, bounce, id, ph, ro, rd, rtime, xw, klo, khi, no, nd); \
       Affine f;  /* loaded after the material code, which is where the registers are scarce */                  \
-      quad_load_map<B0>(P, entry, lane, bounce, f);                                                                  \
+      quad_load_map<B0>(P, entry, lane, bounce, stage, f);                                                                  \
       if (valid) {                                                                                               \
         if (cont) {                                                                                              \
           const float e0[3] = {0.f, 0.f, 0.f};                                                                   \
@@ -1729,9 +1737,9 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_ti
       {                                                                                                          \
         QuadRecord q;                                                                                            \
         ray_pack(q, no, nd, rtime, id);                                                                          \
-        quad_store<(int)sizeof(PathRay), 4>(ray_out, out, lane, q);                                              \
+        quad_store<(int)sizeof(PathRay), 4>(ray_out, out, lane, stage, q);                                            \
         affine_pack(q, f);                                                                                       \
-        quad_store<(int)sizeof(PathMap), 3>(st_out, out, lane, q);                                               \
+        quad_store<(int)sizeof(PathMap), 3>(st_out, out, lane, stage, q);                                             \
       }                                                                                                          \
     }                                                                                                            \
   }
@@ -1751,7 +1759,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_ti
         uint32_t id = entry;
         if (valid && !B0) id = reinterpret_cast<const uint4*>(ray_in + entry)[3].z;
         Affine f;
-        quad_load_map<B0>(P, entry, lane, bounce, f);
+        quad_load_map<B0>(P, entry, lane, bounce, stage, f);
         float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
         if (valid) finish_path(P, id, f, bg);
       }
