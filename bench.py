@@ -27,7 +27,7 @@ pkg = importlib.import_module("rust-raytracer_amd")
 # Device record sizes that define the algorithmic bytes of one ray segment of the traversal kernel.
 BYTES_BVH_NODE = 64    # DTNode: f32 boxes of both children (2 x 6 f32) + two child refs, one 64-B record per visit
 BYTES_SPHERE = 64      # the part of DSphere a test reads: centre, motion, radius (7 f64) + material word
-BYTES_SEGMENT_STATE = 64 + 4 + 16  # PathRay record read, live-queue entry read, PathHit record write
+BYTES_SEGMENT_STATE = 64 + 16  # PathRay record read (it carries the path id; not at bounce 0, whose rays are computed), PathHit record write
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # HBM bytes per launch of the traversal kernel on the default workload (1920x1080, 64-strata batches, depth 50),
 # from rocprofv3 PMC passes of this build (2 x FETCH_SIZE + WRITE_SIZE, in KB, summed over the launches of one

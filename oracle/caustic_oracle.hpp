@@ -496,6 +496,8 @@ struct Node {  // object/mod.rs:54-68
   virtual const AABB& bounding_box() const = 0;
   virtual double pdf_value(RenderContext&, const Vec3&, const Vec3&) const { return 0.0; }
   virtual Vec3 random(RenderContext&, const Vec3&) const { return Vec3(1.0, 0.0, 0.0); }
+  // Adds v to the number of times one world.hit reaches every ConstantMedium below this node.
+  virtual void count_tests(int) {}
 };
 using NodeP = std::shared_ptr<Node>;
 
@@ -797,6 +799,7 @@ struct Group : Node {
     bbox = AABB::from_boxes(bbox, nb);
   }
   int kind() const override { return K_GROUP; }
+  void count_tests(int v) override { for (const NodeP& n : nodes) n->count_tests(v); }
   // group.rs:44-54
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     bool any = false;
@@ -1031,6 +1034,7 @@ struct Translate : Node {
   // translate.rs:15-22
   Translate(NodeP o, const Vec3& off) : object(std::move(o)), offset(off) { bbox = object->bounding_box().translated(off); }
   int kind() const override { return K_TRANSLATE; }
+  void count_tests(int v) override { object->count_tests(v); }
   // translate.rs:26-37
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     Ray offset_r(ray.origin - offset, ray.direction, ray.time);
@@ -1086,6 +1090,7 @@ struct Rotate : Node {
     return AABB::from_points(mn, mx);
   }
   int kind() const override { return K_ROTATE; }
+  void count_tests(int v) override { object->count_tests(v); }
   // rotate.rs:135-149
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     Ray rotated_r(inv.mul(ray.origin), inv.mul(ray.direction), ray.time);
@@ -1118,6 +1123,7 @@ struct Scale : Node {
     bbox = AABB::pad_to_minimums(AABB{ix, iy, iz});
   }
   int kind() const override { return K_SCALE; }
+  void count_tests(int v) override { object->count_tests(v); }
   // scale.rs:95-117: t is kept; the normal goes through the inverse matrix and is re-normalised
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     Ray scaled_r(inv.mul(ray.origin), inv.mul(ray.direction), ray.time);
@@ -1139,6 +1145,13 @@ struct ConstantMedium : Node {
   ConstantMedium(NodeP b, double density, std::shared_ptr<Texture> tex)
       : boundary(std::move(b)), neg_inv_density(-1.0 / density), phase_function(std::make_shared<Isotropic>(std::move(tex))) {}
   int kind() const override { return K_MEDIUM; }
+  // The reference draws a fresh free-flight sample on every test and keeps the nearest hit; one world.hit tests
+  // a medium more than once when a BoundingVolumeHierarchy holds it as both children (bvh.rs:22-26).  `tests`
+  // is that count (set by count_tests from the world root); hit() takes the nearest of `tests` keyed samples
+  // every time it is called, which has the same distribution as the reference's sequence of tests and makes
+  // the outcome independent of the visiting order.
+  int tests = 0;
+  void count_tests(int v) override { tests += v; }
   // constant_medium.rs:41-80
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     HitRecord hit1, hit2;
@@ -1150,7 +1163,9 @@ struct ConstantMedium : Node {
     if (hit1.t < 0.0) hit1.t = 0.0;
     double ray_length = ray.direction.length();
     double distance_inside_boundary = (hit2.t - hit1.t) * ray_length;
-    double hit_distance = neg_inv_density * std::log(ctx.random->rand_keyed((uint32_t)id));
+    double u = ctx.random->rand_keyed((uint32_t)id);
+    for (int j = 1; j < tests; j++) u = std::fmax(u, ctx.random->rand_keyed((uint32_t)id | ((uint32_t)j << 24)));
+    double hit_distance = neg_inv_density * std::log(u);
     if (hit_distance > distance_inside_boundary) return false;
     double t = hit1.t + hit_distance / ray_length;
     rec.pt = ray.at(t);
@@ -1206,6 +1221,7 @@ struct BVH : Node {
     return ia < ib;
   }
   int kind() const override { return K_BVH; }
+  void count_tests(int v) override { left->count_tests(v); right->count_tests(v); }  // a single object is both children
   // bvh.rs:58-76
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     ctx.n_bvh_visits++;

@@ -200,6 +200,9 @@ int orc_constant_medium_tex(OrcScene* s, int boundary, double density, int tex) 
 int orc_scene_set_world(OrcScene* s, int node) {
   CHECK_NODE(node);
   s->world = s->nodes[node];
+  for (auto& n : s->nodes)
+    if (n && n->kind() == K_MEDIUM) static_cast<ConstantMedium*>(n.get())->tests = 0;
+  s->world->count_tests(1);
   return 0;
 }
 int orc_scene_set_lights(OrcScene* s, int node) {

@@ -120,6 +120,8 @@ struct alignas(8) DMedium {
   uint32_t mat;  // Isotropic material
   nref_t xform;
   int32_t leaf_id;
+  uint32_t tests;  // times one world.hit of the reference tests this medium, each with a fresh free-flight sample
+  uint32_t pad;
 };
 
 enum : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_DIFFUSE_LIGHT = 3, MK_ISOTROPIC = 4, MK_EMPTY = 5, MK_COUNT = 6 };

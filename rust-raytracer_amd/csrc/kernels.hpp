@@ -796,7 +796,13 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
             if (t1 < 0.0) t1 = 0.0;
             double ray_length = len(r.d);
             double inside = (t2 - t1) * ray_length;
-            double hit_distance = m.neg_inv_density * log(rng.keyed((uint32_t)m.leaf_id));
+            // The reference draws one sample per test of the medium and keeps the nearest hit, and it tests a
+            // medium more than once per world.hit when the medium is the only object of a BoundingVolumeHierarchy
+            // (m.tests).  The nearest of those exponential samples comes from the largest uniform; taking all of
+            // them on every visit makes the visit idempotent and independent of the visiting order.
+            double u = rng.keyed((uint32_t)m.leaf_id);
+            for (uint32_t j = 1; j < m.tests; j++) u = fmax(u, rng.keyed((uint32_t)m.leaf_id | (j << 24)));
+            double hit_distance = m.neg_inv_density * log(u);
             if (!(hit_distance > inside)) {
               best_t = t1 + hit_distance / ray_length;
               best = node;

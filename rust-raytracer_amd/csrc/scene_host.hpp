@@ -478,7 +478,9 @@ struct HostScene {
 
     // h: host index; xform: innermost transform ancestor; in_boundary: inside a medium's boundary subtree;
     // leaf_override: creation id reported for hits (a box reports its own id for its faces).
-    nref_t emit(int h, nref_t xform, bool in_boundary, int leaf_override) {
+    // tests: how often one world.hit of the reference reaches this node (a BoundingVolumeHierarchy over a single
+    // object holds it as both children, bvh.rs:22-26, and visits both); only a ConstantMedium cares.
+    nref_t emit(int h, nref_t xform, bool in_boundary, int leaf_override, uint32_t tests = 1) {
       const HNode& n = H.nodes[h];
       switch (n.kind) {
         case CHIP_NODE_SPHERE: return emit_sphere(n, xform, leaf_override >= 0 ? leaf_override : n.id);
@@ -491,7 +493,7 @@ struct HostScene {
           int lo = (n.kind == CHIP_NODE_BOX || n.kind == CHIP_NODE_CONE) ? n.id : leaf_override;
           std::vector<nref_t> refs;
           refs.reserve(n.kids.size());
-          for (int k : n.kids) refs.push_back(emit(k, xform, in_boundary, lo));
+          for (int k : n.kids) refs.push_back(emit(k, xform, in_boundary, lo, tests));
           DGroup g;
           g.first = (uint32_t)F.gchild.size();
           g.count = (uint32_t)refs.size();
@@ -505,8 +507,8 @@ struct HostScene {
           F.bvh_child_box[0].push_back(H.nodes[n.c0].box);
           F.bvh_child_box[1].push_back(H.nodes[n.c1].box);
           F.bvh_is_root.push_back(n.id >= 0 ? 1 : 0);
-          nref_t l = emit(n.c0, xform, in_boundary, leaf_override);
-          nref_t r = n.c1 == n.c0 ? l : emit(n.c1, xform, in_boundary, leaf_override);
+          nref_t l = emit(n.c0, xform, in_boundary, leaf_override, n.c1 == n.c0 ? 2 * tests : tests);
+          nref_t r = n.c1 == n.c0 ? l : emit(n.c1, xform, in_boundary, leaf_override, tests);
           DBvhNode& b = F.bvh[idx];
           for (int i = 0; i < 6; i++) b.box[i] = n.box.v[i];
           b.left = l;
@@ -557,7 +559,7 @@ struct HostScene {
             t.chain_first = cf;
             t.chain_len = (uint32_t)chain.size();
           }
-          nref_t c = emit(n.c0, self, in_boundary, leaf_override);
+          nref_t c = emit(n.c0, self, in_boundary, leaf_override, tests);
           if (n.kind == CHIP_NODE_TRANSLATE) F.translates[idx].child = c;
           else if (n.kind == CHIP_NODE_ROTATE) F.rotates[idx].child = c;
           else F.scales[idx].child = c;
@@ -574,6 +576,7 @@ struct HostScene {
           m.mat = MATK_PACK(n.mat, H.materials[n.mat].kind);
           m.xform = xform;
           m.leaf_id = n.id;
+          m.tests = tests;
           return NREF(NK_MEDIUM, idx);
         }
       }

@@ -1,0 +1,51 @@
+"""A ConstantMedium draws a fresh free-flight sample every time it is tested (constant_medium.rs:41-80), and a
+BoundingVolumeHierarchy built over a single object holds that object as both children and visits both
+(bvh.rs:22-26, 58-76).  A medium that is alone in a hierarchy is therefore tested twice per world.hit and
+scatters as if it were twice as dense; the oracle and the device both have to reproduce that.
+Parity unpinned above the math level: the reference has no test for this; the expected transmission follows
+from the two cited pieces of code."""
+import numpy as np
+import pytest
+
+
+def _scene(be, alone: bool, density=0.5):
+    sc = be.new_scene()
+    boundary = sc.sphere((0.0, 0.0, 0.0), 1.0, sc.lambertian_color(0.5, 0.5, 0.5))
+    medium = sc.constant_medium_color(boundary, density, 1.0, 1.0, 1.0)
+    members = [medium] if alone else [medium, sc.sphere((0.0, 50.0, 0.0), 1.0, sc.lambertian_color(0.5, 0.5, 0.5))]
+    sc.set_world(sc.bvh(members))
+    sc.set_camera(image_width=8, samples_per_pixel=1, max_depth=2, look_from=(0, 0, 20), look_at=(0, 0, 0), background=(1, 1, 1))
+    sc.commit()
+    return sc
+
+
+def _rays(n):
+    # through the centre of the unit sphere along +z: 2 units inside the boundary
+    o = np.tile(np.array([[0.0, 0.0, -5.0]]), (n, 1))
+    d = np.tile(np.array([[0.0, 0.0, 1.0]]), (n, 1))
+    # generic directions (no zero component) that still pass close to the centre
+    rng = np.random.default_rng(5)
+    d[:, :2] = rng.uniform(1e-3, 2e-3, (n, 2))
+    return o, d
+
+
+@pytest.mark.parametrize("alone,expected", [(True, np.exp(-2.0)), (False, np.exp(-1.0))])
+def test_oracle_transmission_through_medium(oracle, alone, expected):
+    n = 40_000
+    o, d = _rays(n)
+    hits = _scene(oracle, alone).trace_rays(o, d, seed=3)
+    transmitted = 1.0 - hits["hit"].mean()
+    assert abs(transmitted - expected) < 4.0 * np.sqrt(expected * (1.0 - expected) / n) + 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alone", [True, False])
+def test_gpu_medium_hits_equal_oracle(oracle, gpu, alone):
+    n = 40_000
+    o, d = _rays(n)
+    want = _scene(oracle, alone).trace_rays(o, d, seed=3)
+    got = _scene(gpu, alone).trace_rays(o, d, seed=3)
+    assert np.array_equal(got["hit"], want["hit"])
+    m = want["hit"] == 1
+    assert m.any() and (~m).any()
+    assert np.array_equal(got["t"][m], want["t"][m])
