@@ -813,11 +813,21 @@ struct HostScene {
       std::sort(slots.begin(), slots.end());
       // drop members with an empty box (the two empty Groups of an empty hierarchy, bvh.rs:23-26)
       leaves.erase(std::remove_if(leaves.begin(), leaves.end(), [](const SahLeaf& l) { return !(l.box.v[0] <= l.box.v[1]); }), leaves.end());
-      if (leaves.empty()) continue;
+      if (leaves.empty()) {
+        // an empty hierarchy: its reference children (two empty Groups) stand in, behind boxes every ray hits;
+        // visiting them does nothing, whereas an absent child would read as the end of the traversal
+        F.tnodes[root].left = F.bvh[root].left;
+        F.tnodes[root].right = F.bvh[root].right;
+        continue;
+      }
       if (leaves.size() == 1) {
+        // Both children are the member, as in the reference (bvh.rs:27-28).  An absent child cannot be expressed
+        // by an inverted box: the slab test orders each axis's two plane distances with min / max, so an
+        // inverted box is one that every ray hits.
         DTNode& t = F.tnodes[root];
-        t.left = leaves[0].ref;
+        t.left = t.right = leaves[0].ref;
         set_cull_box(t.lbox, leaves[0].box);
+        set_cull_box(t.rbox, leaves[0].box);
         continue;
       }
       // breadth-first construction; node k of this hierarchy takes the k-th smallest slot

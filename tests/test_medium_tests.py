@@ -48,4 +48,31 @@ def test_gpu_medium_hits_equal_oracle(oracle, gpu, alone):
     assert np.array_equal(got["hit"], want["hit"])
     m = want["hit"] == 1
     assert m.any() and (~m).any()
+    # the free-flight distance goes through log(): the device's and the host's differ in the last bits
+    assert np.abs(got["t"][m] - want["t"][m]).max() <= 1e-12 * np.abs(want["t"][m]).max()
+
+
+@pytest.mark.gpu
+def test_gpu_single_member_and_empty_hierarchies(oracle, gpu):
+    """Hierarchies over one object and over none (bvh.rs:22-28) nested in a larger world."""
+    def build(be):
+        sc = be.new_scene()
+        lam = sc.lambertian_color(0.5, 0.5, 0.5)
+        single = sc.bvh([sc.sphere((0.0, 0.0, 0.0), 1.0, lam)])
+        empty = sc.bvh([])
+        others = [sc.sphere((3.0 * i - 6.0, 0.5 * i, -2.0), 0.8, lam) for i in range(5)]
+        sc.set_world(sc.group([empty, single, sc.bvh(others), sc.bvh([])]))
+        sc.set_camera(image_width=8, samples_per_pixel=1, max_depth=2, look_from=(0, 0, 20), look_at=(0, 0, 0), background=(1, 1, 1))
+        sc.commit()
+        return sc
+    rng = np.random.default_rng(11)
+    n = 20_000
+    o = rng.uniform(-8.0, 8.0, (n, 3)) + np.array([0.0, 0.0, 12.0])
+    d = rng.uniform(-4.0, 4.0, (n, 3)) - o
+    want = build(oracle).trace_rays(o, d, seed=1)
+    got = build(gpu).trace_rays(o, d, seed=1)
+    assert want["hit"].sum() > 100
+    assert np.array_equal(got["hit"], want["hit"])
+    assert np.array_equal(got["leaf_id"], want["leaf_id"])
+    m = want["hit"] == 1
     assert np.array_equal(got["t"][m], want["t"][m])
