@@ -92,7 +92,10 @@ RENDER_EXACT_SHADING = 2  # shade kernels keep the reference's f64 operation ord
 RENDER_REFERENCE_ORDER = 4  # literal replay of the reference's traversal order instead of the ordered traversal
 RENDER_QUANTISE_255 = 8  # 8-bit output scaled by 255.0 (wasm caller) instead of 255.999 (CLI)
 
-NODE_KIND_NAMES = {0: "bvh", 1: "sphere", 2: "quad", 3: "group", 4: "translate", 5: "rotate", 6: "medium", 7: "box"}
+NODE_KIND_NAMES = {0: "bvh", 1: "sphere", 2: "quad", 3: "group", 4: "translate", 5: "rotate", 6: "medium", 7: "box", 8: "disc", 9: "cone",
+                   10: "cone_wall", 11: "scale"}
+(NODE_BVH, NODE_SPHERE, NODE_QUAD, NODE_GROUP, NODE_TRANSLATE, NODE_ROTATE, NODE_MEDIUM, NODE_BOX, NODE_DISC, NODE_CONE, NODE_CONE_WALL,
+ NODE_SCALE) = range(12)  # CHIP_NODE_* of include/caustic_hip.h
 
 
 class CausticError(RuntimeError):

@@ -480,7 +480,19 @@ SCENES = {
 
 
 def build(backend, name, **kw):
-    """Creates, fills and commits a scene on `backend`."""
+    """Creates, fills and commits a scene on `backend`.  `name` is one of SCENES or the path of a `.scad` file,
+    the two forms the reference's command line takes (crates/cli/src/main.rs:30-62)."""
+    if name.endswith(".scad"):
+        from . import scad  # (scad imports this module)
+        import os
+        folder = os.path.dirname(os.path.abspath(name))
+        loader = kw.pop("image_loader", None)
+        with open(name) as fh:
+            sc, messages = scad.run_openscad(fh.read(), backend, scene_seed=kw.pop("seed", 1), image_loader=loader)
+        errors = [text for level, text in messages if level == "error"]
+        if errors:
+            raise scad.ScadError(f"{os.path.basename(name)} in {folder}: " + "; ".join(errors))
+        return sc
     sc = backend.new_scene()
     SCENES[name](sc, **kw)
     sc.commit()

@@ -1,0 +1,157 @@
+"""The `.scad` reader (rust-raytracer_amd/scad.py) against the known answers of the reference's own interpreter
+tests (crates/openscad/src/interpreter/tests.rs, extracted by tests/golden/make_scad_vectors.py), plus the shape of
+the scenes it builds and device / oracle agreement on such a scene."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+VECTORS = json.load(open(os.path.join(HERE, "golden", "scad_vectors.json")))
+
+
+@pytest.fixture(scope="module")
+def scad(pkg):
+    return importlib.import_module(pkg.__name__ + ".scad")
+
+
+def test_reference_echo_vectors(scad, oracle):
+    assert len(VECTORS) >= 130
+    for v in VECTORS:
+        out = scad.echo_output(v["source"], oracle)
+        if v["trim"]:
+            assert out.strip() == v["expected"], (v["line"], v["source"])
+        else:
+            assert out == v["expected"], (v["line"], v["source"])
+
+
+def test_mt19937_64_default_seed(scad):
+    # the generator's published check values for the default seed 5489: first output, and the 10000th
+    g = scad.Mt64()
+    first = g.next_u64()
+    assert first == 14514284786278117030
+    for _ in range(9998):
+        g.next_u64()
+    assert g.next_u64() == 9981545732273789042
+
+
+def test_unary_minus_takes_the_whole_expression(scad, oracle):
+    # parser.rs:841-856
+    assert scad.echo_output("a = 2; b = 5; echo(-a + b);", oracle).strip() == "-7"
+    assert scad.echo_output("echo(10 - 0.5);", oracle).strip() == "9.5"
+
+
+def test_for_excludes_its_end_and_blocks_share_one_scope(scad, oracle):
+    assert scad.echo_output("for (i = [0 : 3]) { echo(i); }", oracle).split() == ["0", "1", "2"]
+    assert scad.echo_output("for (i = [3 : -1 : 0]) echo(i);", oracle).split() == ["3", "2", "1"]
+    assert scad.echo_output("for (i = [0 : 2]) { last = i; } echo(last);", oracle).strip() == "1"
+
+
+def test_rands_follow_the_unseeded_generator(scad, oracle):
+    g = scad.Mt64()
+    want = [2.0 + (float(g.next_u64()) / 18446744073709551615.0) * 3.0 for _ in range(3)]
+    out = scad.echo_output("echo(rands(2, 5, 3));", oracle).strip()
+    assert out == "[" + ", ".join(scad.format_value(x) for x in want) + "]"
+
+
+def _tree(sc):
+    kinds, ids, boxes = sc.dump_tree()
+    return list(kinds), boxes
+
+
+def test_circle_becomes_a_disc(scad, oracle, pkg):
+    # interpreter/tests.rs:47-61
+    sc, msgs = scad.run_openscad("circle(r=20);", oracle)
+    assert msgs == []
+    kinds, boxes = _tree(sc)
+    b = pkg.bindings
+    assert kinds[0] == b.NODE_BVH and kinds[1] == b.NODE_DISC
+    assert np.allclose(boxes[1][[0, 1]], [-20.0, 20.0])
+
+
+def test_axis_swap_and_default_camera(scad, oracle):
+    # value.rs:103-104: OpenSCAD [x, y, z] -> (-x, z, y); default camera mod.rs:175-185 (600 x 600)
+    sc, msgs = scad.run_openscad("translate([1, 2, 3]) sphere(r=0.5);", oracle)
+    assert msgs == []
+    assert sc.image_size() == (600, 600)
+    _, boxes = _tree(sc)
+    assert np.allclose(boxes[0], [-1.5, -0.5, 2.5, 3.5, 1.5, 2.5])
+
+
+CAR_LIKE = """
+$fa = 1; $fs = 0.4;
+include <caustic.scad>
+camera(image_width = 48, image_height = 32, samples_per_pixel = 4, max_depth = 5, vertical_fov = 60.0,
+       look_from = [50.0, -50.0, 70.0], look_at = [0, 0, 0], up = [0, 0, 1], background = [0.7, 0.8, 1.0]);
+color([1, 0, 0]) cube([200, 1, 1], center=true);
+color([0, 125, 255] / 255) scale([1.2, 1, 1]) cube([60, 20, 10], center=true);
+translate([5, 0, 10 - 0.001]) cube([30, 20, 10], center=true);
+for (sx = [-20 : 40 : 21]) {
+  for (sy = [-15 : 30 : 16]) {
+    translate([sx, sy, 0]) rotate([90, 0, 0]) cylinder(h=3, r=8, center=true);
+  }
+  metal(c=[0.8, 0.8, 0.8], fuzz=0.1) translate([sx, 0, 0]) rotate([90, 0, 0]) cylinder(h=30, r1=2, r2=1.5, center=true);
+}
+function dist(p, q) = sqrt(pow(q[0]-p[0], 2) + pow(q[1]-p[1], 2));
+for (a = [-3 : 3]) {
+  c = [a * 12 + rands(0, 1, 1)[0], 40 + 5 * rands(0, 1, 1)[0], 4];
+  if (dist(c, [0, 40]) > 5) {
+    if (rands(0, 1, 1)[0] < 0.5) { lambertian(rands(0, 1, 3) * rands(0, 1, 3)) translate(c) sphere(r=4); }
+    else { dielectric(1.5) translate(c) sphere(d=8); }
+  }
+}
+lambertian(t=checker(scale=8, even=[0.2, 0.3, 0.1], odd=[0.9, 0.9, 0.9])) translate([0, 0, -1005]) sphere(r=1000);
+translate([-40, 30, 0]) circle(d=20);
+diffuse_light(c=[4, 4, 4]) quad(q=[-30, -40, 1], u=[20, 0, 0], v=[0, 0, 20]);
+"""
+
+
+def _rays(n=20_000):
+    rng = np.random.default_rng(3)
+    o = np.array([50.0, 70.0, -50.0]) + rng.uniform(-5, 5, (n, 3))  # near the swapped look_from
+    target = rng.uniform(-45, 45, (n, 3)) * np.array([1.0, 0.3, 1.0])
+    return o, target - o
+
+
+def test_car_like_scene_builds_on_the_oracle(scad, oracle):
+    sc, msgs = scad.run_openscad(CAR_LIKE, oracle)
+    assert msgs == []
+    assert sc.image_size() == (48, 32)
+    o, d = _rays(4000)
+    hits = sc.trace_rays(o, d, seed=1)
+    assert 0.5 < hits["hit"].mean() <= 1.0
+
+
+@pytest.mark.gpu
+def test_gpu_scad_scene_equals_oracle(scad, oracle, gpu):
+    want_sc, _ = scad.run_openscad(CAR_LIKE, oracle)
+    got_sc, msgs = scad.run_openscad(CAR_LIKE, gpu)
+    assert msgs == []
+    wk, wb = _tree(want_sc)
+    gk, gb = _tree(got_sc)
+    assert wk == gk and np.array_equal(wb, gb)  # the same tree, box for box
+    o, d = _rays()
+    want = want_sc.trace_rays(o, d, seed=1)
+    got = got_sc.trace_rays(o, d, seed=1)
+    assert np.array_equal(got["hit"], want["hit"])
+    assert np.array_equal(got["leaf_id"], want["leaf_id"])
+    m = want["hit"] == 1
+    assert np.abs(got["t"][m] - want["t"][m]).max() <= 1e-5 * np.abs(want["t"][m]).max()
+    assert np.abs(got["normal"][m] - want["normal"][m]).max() <= 1e-5
+    img_w, _, st_w = want_sc.render_frame(seed=5, sum_dtype=np.float64)
+    img_g, _, st_g = got_sc.render_frame(seed=5, flags=2)  # exact shading arithmetic
+    bad = np.abs(img_g.astype(np.float64) - img_w) > 1e-3 * (1.0 + np.abs(img_w))
+    assert bad.mean() < 5e-3
+
+
+def test_scene_builder_takes_a_scad_path(pkg, oracle, tmp_path):
+    path = tmp_path / "two.scad"
+    path.write_text("camera(image_width=20, image_height=10);\nsphere(r=2);\ntranslate([5, 0, 0]) cube(2);\n")
+    sc = pkg.scenes.build(oracle, str(path))
+    assert sc.image_size() == (20, 10)
+    bad = tmp_path / "bad.scad"
+    bad.write_text("nonsense(1);\n")
+    with pytest.raises(Exception):
+        pkg.scenes.build(oracle, str(bad))
