@@ -1,5 +1,5 @@
 """The oracle against every executable assertion the reference holds for the hot path: the doctests of
-crates/core's math value types, the sphere UV table and the RNG contracts (SURVEY section 8c list).
+crates/core's math value types, the sphere UV table and the RNG contracts.
 Above this level the reference has no vectors, so the oracle is 'parity unpinned' there."""
 import ctypes as C
 import math
