@@ -48,8 +48,9 @@ struct alignas(16) PathHit {  // what traversal writes: closest hit of the curre
                   // consumed during traversal (media free-flight samples)
 };
 #define PATHHIT_DRAW(info) ((info) >> 24)
-struct alignas(16) PathMap {  // x -> clamp(a + b x, lo, hi), the composed radiance map of the path so far
-  float a[3], b[3], lo[3], hi[3];
+struct alignas(16) PathMap {  // x -> clamp(b x, lo, hi), the composed radiance map of the path so far, and the path id
+  uint32_t id, pad[2];
+  float b[3], lo[3], hi[3];
 };
 struct PathPool {
   PathRay* ray[2];  // [cap] each: entries of even / odd bounces
@@ -1135,26 +1136,27 @@ __device__ inline void queue_push(uint32_t* q, uint32_t* counter, bool pred, uin
 
 __device__ inline float fclampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }  // keeps NaN like f64::clamp
 
+// The radiance map of a path that is still alive has no constant term: a material that scatters emits nothing
+// (material/mod.rs default `emitted`), and the one that emits (diffuse_light.rs:28-43) ends the path.
 struct Affine {
-  float a[3], b[3], lo[3], hi[3];
+  float b[3], lo[3], hi[3];
 };
-// One bounce of camera.rs:274-304 as the per-channel map x -> clamp(e + w x, klo, khi),
-// composed on the right of the path's x -> clamp(a + b x, lo, hi).
-__device__ inline void affine_compose(Affine& f, const float e[3], const float w[3], float klo, float khi) {
+// One bounce of camera.rs:274-304 as the per-channel map x -> clamp(w x, klo, khi),
+// composed on the right of the path's x -> clamp(b x, lo, hi).
+__device__ inline void affine_compose(Affine& f, const float w[3], float klo, float khi) {
 #pragma unroll
   for (int c = 0; c < 3; c++) {
-    float p = f.a[c] + f.b[c] * klo, q = f.a[c] + f.b[c] * khi;
+    float p = f.b[c] * klo, q = f.b[c] * khi;
     float nlo = fclampf(p < q ? p : q, f.lo[c], f.hi[c]);
     float nhi = fclampf(p < q ? q : p, f.lo[c], f.hi[c]);
-    f.a[c] = f.a[c] + f.b[c] * e[c];
     f.b[c] = f.b[c] * w[c];
     f.lo[c] = nlo;
     f.hi[c] = nhi;
   }
 }
 __device__ inline void finish_path(const PathPool& P, uint32_t slot, const Affine& f, const float x[3]) {
-  P.sample[slot] = make_float4(fclampf(f.a[0] + f.b[0] * x[0], f.lo[0], f.hi[0]), fclampf(f.a[1] + f.b[1] * x[1], f.lo[1], f.hi[1]),
-                               fclampf(f.a[2] + f.b[2] * x[2], f.lo[2], f.hi[2]), 0.f);
+  P.sample[slot] = make_float4(fclampf(f.b[0] * x[0], f.lo[0], f.hi[0]), fclampf(f.b[1] * x[1], f.lo[1], f.hi[1]),
+                               fclampf(f.b[2] * x[2], f.lo[2], f.hi[2]), 0.f);
 }
 // 16-byte accesses of a ray record
 __device__ inline void ray_load(const PathRay* rec, V3& o, V3& d, double& time, uint32_t& id) {
@@ -1263,30 +1265,31 @@ __device__ inline void ray_pack(QuadRecord& q, V3 o, V3 d, double time, uint32_t
   d2u(d.y, q.w[2][0], q.w[2][1]); d2u(d.z, q.w[2][2], q.w[2][3]);
   d2u(time, q.w[3][0], q.w[3][1]); q.w[3][2] = id; q.w[3][3] = 0;
 }
-__device__ inline void affine_unpack(const QuadRecord& q, Affine& f) {
-  f.a[0] = __uint_as_float(q.w[0][0]); f.a[1] = __uint_as_float(q.w[0][1]); f.a[2] = __uint_as_float(q.w[0][2]); f.b[0] = __uint_as_float(q.w[0][3]);
+__device__ inline void affine_unpack(const QuadRecord& q, Affine& f, uint32_t& id) {
+  id = q.w[0][0]; f.b[0] = __uint_as_float(q.w[0][3]);
   f.b[1] = __uint_as_float(q.w[1][0]); f.b[2] = __uint_as_float(q.w[1][1]); f.lo[0] = __uint_as_float(q.w[1][2]); f.lo[1] = __uint_as_float(q.w[1][3]);
   f.lo[2] = __uint_as_float(q.w[2][0]); f.hi[0] = __uint_as_float(q.w[2][1]); f.hi[1] = __uint_as_float(q.w[2][2]); f.hi[2] = __uint_as_float(q.w[2][3]);
 }
-__device__ inline void affine_pack(QuadRecord& q, const Affine& f) {
-  q.w[0][0] = __float_as_uint(f.a[0]); q.w[0][1] = __float_as_uint(f.a[1]); q.w[0][2] = __float_as_uint(f.a[2]); q.w[0][3] = __float_as_uint(f.b[0]);
+__device__ inline void affine_pack(QuadRecord& q, const Affine& f, uint32_t id) {
+  q.w[0][0] = id; q.w[0][1] = 0u; q.w[0][2] = 0u; q.w[0][3] = __float_as_uint(f.b[0]);
   q.w[1][0] = __float_as_uint(f.b[1]); q.w[1][1] = __float_as_uint(f.b[2]); q.w[1][2] = __float_as_uint(f.lo[0]); q.w[1][3] = __float_as_uint(f.lo[1]);
   q.w[2][0] = __float_as_uint(f.lo[2]); q.w[2][1] = __float_as_uint(f.hi[0]); q.w[2][2] = __float_as_uint(f.hi[1]); q.w[2][3] = __float_as_uint(f.hi[2]);
   q.w[3][0] = 0; q.w[3][1] = 0; q.w[3][2] = 0; q.w[3][3] = 0;
 }
 __device__ inline void affine_identity(Affine& f) {
 #pragma unroll
-  for (int c = 0; c < 3; c++) { f.a[c] = 0.f; f.b[c] = 1.f; f.lo[c] = -CHIP_BIG; f.hi[c] = CHIP_BIG; }
+  for (int c = 0; c < 3; c++) { f.b[c] = 1.f; f.lo[c] = -CHIP_BIG; f.hi[c] = CHIP_BIG; }
 }
 // The radiance map of every lane's entry of `bounce` (the identity before the first bounce, never stored).
 template <bool B0>
-__device__ inline void quad_load_map(const PathPool& P, uint32_t entry, uint32_t lane, uint32_t bounce, uint4* stage, Affine& f) {
+__device__ inline void quad_load_map(const PathPool& P, uint32_t entry, uint32_t lane, uint32_t bounce, uint4* stage, Affine& f, uint32_t& id) {
   if (B0) {
     affine_identity(f);
+    id = entry;  // at bounce 0 entry i is path i
   } else {
     QuadRecord q;
     quad_load<(int)sizeof(PathMap), 3>(P.st[bounce & 1], entry, lane, stage, q);
-    affine_unpack(q, f);
+    affine_unpack(q, f, id);
   }
 }
 
@@ -1728,11 +1731,10 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_ti
       bool cont = false;                                                                                         \
       if (valid) cont = shade_hit<KIND, FAST, LEAN, EXT>(S, B, bounce, id, ph, ro, rd, rtime, xw, klo, khi, no, nd); \
       Affine f;  /* loaded after the material code, which is where the registers are scarce */                  \
-      quad_load_map<B0>(P, entry, lane, bounce, stage, f);                                                                  \
+      quad_load_map<B0>(P, entry, lane, bounce, stage, f, id);                                                   \
       if (valid) {                                                                                               \
         if (cont) {                                                                                              \
-          const float e0[3] = {0.f, 0.f, 0.f};                                                                   \
-          affine_compose(f, e0, xw, klo, khi);                                                                   \
+          affine_compose(f, xw, klo, khi);                                                                       \
           xw[0] = 0.f; xw[1] = 0.f; xw[2] = 0.f;                                                                 \
           cont = !last_bounce;  /* camera.rs:259-261 */                                                          \
         }                                                                                                        \
@@ -1744,7 +1746,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_ti
         QuadRecord q;                                                                                            \
         ray_pack(q, no, nd, rtime, id);                                                                          \
         quad_store<(int)sizeof(PathRay), 4>(ray_out, out, lane, stage, q);                                            \
-        affine_pack(q, f);                                                                                       \
+        affine_pack(q, f, id);                                                                                   \
         quad_store<(int)sizeof(PathMap), 3>(st_out, out, lane, stage, q);                                             \
       }                                                                                                          \
     }                                                                                                            \
@@ -1763,9 +1765,8 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_ti
         const bool valid = k < bin_end;
         const uint32_t entry = valid ? tile0 + s_order[k] : CHIP_NO_SLOT;
         uint32_t id = entry;
-        if (valid && !B0) id = reinterpret_cast<const uint4*>(ray_in + entry)[3].z;
         Affine f;
-        quad_load_map<B0>(P, entry, lane, bounce, stage, f);
+        quad_load_map<B0>(P, entry, lane, bounce, stage, f, id);  // a miss needs nothing of its ray record
         float bg[3] = {(float)S.cam.background[0], (float)S.cam.background[1], (float)S.cam.background[2]};
         if (valid) finish_path(P, id, f, bg);
       }
