@@ -15,6 +15,9 @@
 #define CHIP_BLOCK 256
 #define CHIP_STACK_LDS 16  // per-lane short stack entries kept in LDS
 #define CHIP_STACK_OVF 48  // further entries spill to a per-thread global slab
+#ifndef CHIP_SHADE_PRIO
+#define CHIP_SHADE_PRIO 1  // wave priority of the shade kernel: its few instructions issue ahead of a co-resident traversal kernel's, so its memory requests leave early
+#endif
 #ifndef CHIP_REFILL_THRESH
 #define CHIP_REFILL_THRESH 48  // a traversing wave refills its idle lanes once fewer than this many are busy
 #endif
@@ -1660,6 +1663,9 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
 template <bool FAST, bool LEAN, bool EXT, bool B0>
 __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg) {
   const uint32_t bounce = B0 ? 0u : bounce_arg;
+#if CHIP_SHADE_PRIO
+  __builtin_amdgcn_s_setprio(CHIP_SHADE_PRIO);
+#endif
   const PathRay* ray_in = P.ray[bounce & 1];
   PathRay* ray_out = P.ray[(bounce + 1) & 1];
   PathMap* st_out = P.st[(bounce + 1) & 1];
