@@ -15,6 +15,9 @@
 #define CHIP_BLOCK 256
 #define CHIP_STACK_LDS 16  // per-lane short stack entries kept in LDS
 #define CHIP_STACK_OVF 48  // further entries spill to a per-thread global slab
+#ifndef CHIP_TRAV_PROFILE
+#define CHIP_TRAV_PROFILE 0  // 1: the node / primitive counters count loop trips per wave instead of visits per lane (lane-utilisation study)
+#endif
 #ifndef CHIP_SHADE_PRIO
 #define CHIP_SHADE_PRIO 1  // wave priority of the shade kernel: its few instructions issue ahead of a co-resident traversal kernel's, so its memory requests leave early
 #endif
@@ -649,7 +652,11 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       while (NREF_KIND(node) == NK_BVH) {
         TNodeRec n;
         load_tnode<CACHE>(S, C, NREF_INDEX(node), n);
+#if CHIP_TRAV_PROFILE  /* counts wave-level loop trips instead of per-lane visits */
+        if (__lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) cnt.bvh++;
+#else
         cnt.bvh++;
+#endif
         float el, xl, er, xr;
         cull_slab(n.l, r, el, xl);
         cull_slab(n.r, r, er, xr);
@@ -689,7 +696,11 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
   }
     if (kind == NK_SPHERE) {
       double t;
+#if CHIP_TRAV_PROFILE
+      if (__lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) cnt.prim++;
+#else
       cnt.prim++;
+#endif
       SphereRec sp;
       load_sphere<CACHE>(S, C, idx, sp);
       if (ORD ? sphere_hit_incl(sp, r, tmin, best_t, t) : sphere_hit(sp, r, tmin, best_t, t)) { CHIP_TAKE(node, t, sp.mat) }
