@@ -350,6 +350,7 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       B.npix = npix;
       set_magic(B.npix_magic, npix);
       set_magic(B.rect_w_magic, pl.rw);
+      set_magic(B.sqrt_spp_magic, cam.sqrt_spp);
       B.n_strata = std::min(spb, pl.s_count - sb0);
       B.stratum_first = pl.s_first + sb0 * pl.s_stride;
       B.stratum_stride = pl.s_stride;

@@ -50,10 +50,10 @@ struct alignas(64) PathRay {  // what traversal reads and shading writes
 struct alignas(16) PathHit {  // what traversal writes: closest hit of the current segment
   double t;
   uint32_t node;  // node reference, NREF_NONE = miss
-  uint32_t info;  // bits 0..23: the hit primitive's mat word (material index + kind); bits 24..31: uniforms
-                  // consumed during traversal (media free-flight samples)
+  uint32_t info;  // bits 0..23: the hit primitive's mat word (material index + kind); bits 24..31 (bounce 0 only):
+                  // defocus-disk candidates the camera ray consumed
 };
-#define PATHHIT_DRAW(info) ((info) >> 24)
+#define PATHHIT_TRIES(info) ((info) >> 24)
 struct alignas(16) PathMap {  // x -> clamp(b x, lo, hi), the composed radiance map of the path so far, and the path id
   uint32_t id, pad[2];
   float b[3], lo[3], hi[3];
@@ -77,7 +77,7 @@ struct BatchDesc {
   uint32_t n_strata;                          // strata in this batch
   uint32_t stratum_first, stratum_stride;     // global stratum of batch-local sb: first + sb*stride
   uint32_t n_paths;                           // npix * n_strata
-  uint32_t npix_magic[2], rect_w_magic[2];    // ceil(2^64 / divisor), low and high word (0, 0 for a divisor of 1)
+  uint32_t npix_magic[2], rect_w_magic[2], sqrt_spp_magic[2];  // ceil(2^64 / divisor), low and high word (0, 0 for a divisor of 1)
   uint32_t seed_lo, seed_hi;
   uint32_t reference_order;                   // trace every ray in the reference's own visiting order
 };
@@ -1325,8 +1325,11 @@ __device__ inline void slot_to_path(const BatchDesc& B, const DCamera& cam, uint
 }
 
 // camera.rs:359-374,389-394,416-419 with vector.rs:115-126
+// `tries` is the number of defocus-disk candidates the rejection loop consumed (vector.rs:115-126).  On entry 0 means
+// "run the loop" (the count is returned); a count from an earlier evaluation of the same ray makes this one go
+// straight to the accepted candidate, which in a wave saves the trips the slowest lane needs.
 __device__ inline void camera_ray(const DCamera& cam, Rng& rng, uint32_t x, uint32_t y, uint32_t s_x, uint32_t s_y, V3& o, V3& d,
-                                  double& time) {
+                                  double& time, uint32_t& tries) {
   double px = (((double)s_x + rng.next()) * cam.recip_sqrt_spp) - 0.5;
   double py = (((double)s_y + rng.next()) * cam.recip_sqrt_spp) - 0.5;
   V3 pixel_sample = ld3(cam.pixel00) + (((double)x + px) * ld3(cam.du)) + (((double)y + py) * ld3(cam.dv));
@@ -1334,11 +1337,18 @@ __device__ inline void camera_ray(const DCamera& cam, Rng& rng, uint32_t x, uint
     o = ld3(cam.center);
   } else {
     double dx = 0, dy = 0;
-    for (int it = 0; it < CHIP_REJECT_CAP; it++) {
+    if (tries != 0) {
+      rng.draw += 2u * (tries - 1u);
       dx = rng.interval(-1.0, 1.0);
       dy = rng.interval(-1.0, 1.0);
-      double xs = dx * dx, ys = dy * dy, zs = 0.0 * 0.0;
-      if (xs + ys + zs < 1.0) break;
+    } else {
+      for (int it = 0; it < CHIP_REJECT_CAP; it++) {
+        dx = rng.interval(-1.0, 1.0);
+        dy = rng.interval(-1.0, 1.0);
+        tries++;
+        double xs = dx * dx, ys = dy * dy, zs = 0.0 * 0.0;
+        if (xs + ys + zs < 1.0) break;
+      }
     }
     o = ld3(cam.center) + (dx * ld3(cam.disk_u)) + (dy * ld3(cam.disk_v));
   }
@@ -1349,12 +1359,13 @@ __device__ inline void camera_ray(const DCamera& cam, Rng& rng, uint32_t x, uint
 // The camera ray of path `slot` of a batch (camera.rs:359-374).  Camera rays are never stored: the
 // traversal and the shading of bounce 0 both compute them from the path's Philox stream, which costs a
 // few hundred VALU operations against 192 bytes of HBM traffic per path.
-__device__ inline void path_camera_ray(const DScene& S, const BatchDesc& B, uint32_t slot, V3& o, V3& d, double& time) {
+__device__ inline void path_camera_ray(const DScene& S, const BatchDesc& B, uint32_t slot, V3& o, V3& d, double& time, uint32_t& tries) {
   uint32_t x, y, pixel, stratum;
   slot_to_path(B, S.cam, slot, x, y, pixel, stratum);
   Rng rng;
   rng.init(B.seed_lo, B.seed_hi, pixel, stratum, CHIP_CAMERA_BOUNCE, 0);
-  camera_ray(S.cam, rng, x, y, stratum % S.cam.sqrt_spp, stratum / S.cam.sqrt_spp, o, d, time);
+  const uint32_t s_y = magic_div(stratum, B.sqrt_spp_magic), s_x = stratum - s_y * S.cam.sqrt_spp;
+  camera_ray(S.cam, rng, x, y, s_x, s_y, o, d, time, tries);
 }
 // Starts a batch: every path is live at bounce 0 (entry i is path i; nothing is stored for it yet).
 __global__ void k_begin_batch(PathPool P, BatchDesc B) {
@@ -1447,7 +1458,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
         PathHit ph;
         ph.t = best_t;
         ph.node = best;
-        ph.info = (r.best_mat & 0xFFFFFFu) | ((F & TF_MEDIA) ? (rng.draw << 24) : 0u);
+        ph.info = (r.best_mat & 0xFFFFFFu) | (B0 ? (rng.draw << 24) : 0u);
         *reinterpret_cast<uint4*>(P.hit + entry) = *reinterpret_cast<const uint4*>(&ph);
       }
       has = false;
@@ -1470,7 +1481,8 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
         if (!has && rank < avail) {
           entry = lit_pass ? P.q_lit[w_next + rank] : w_next + rank;
           uint32_t id = entry;  // at bounce 0 entry i is path i
-          if (B0) path_camera_ray(S, B, entry, r.wo, r.wd, r.time);
+          uint32_t tries = 0;
+          if (B0) path_camera_ray(S, B, entry, r.wo, r.wd, r.time, tries);
           else ray_load(ray_in + entry, r.wo, r.wd, r.time, id);
           const bool dead = !B0 && id == CHIP_DEAD_ID;  // reserved by the last shading pass but left empty
           if (dead) *reinterpret_cast<uint4*>(P.hit + entry) = make_uint4(0u, 0u, NREF_DEAD, 0u);
@@ -1494,6 +1506,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
               slot_to_path(B, S.cam, id, x, y, pixel, stratum);
               rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, 0);
             }
+            if (B0) rng.draw = tries;  // rides to the hit record: the bounce-0 shade pass rebuilds the camera ray from it
             best_t = INFINITY;
             best = NREF_NONE;
             node = S.root;
@@ -1556,7 +1569,7 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
     uint32_t x_, y_, pixel, stratum;
     slot_to_path(B, S.cam, slot, x_, y_, pixel, stratum);
     Rng rng;
-    rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, PATHHIT_DRAW(ph.info));
+    rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, 0);  // (the traversal draws nothing from the stream: media samples are keyed)
     V3 ndir;
     bool terminal = false;
     float w[3] = {0.f, 0.f, 0.f};
@@ -1738,7 +1751,9 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_ti
       double rtime = 0.0;                                                                                        \
       uint32_t id = entry;                                                                                       \
       if (B0) {                                                                                                  \
-        if (valid) path_camera_ray(S, B, entry, ro, rd, rtime);                                                  \
+        uint32_t tries = PATHHIT_TRIES(ph.info);                                                                 \
+        ph.info &= 0xFFFFFFu;                                                                                    \
+        if (valid) path_camera_ray(S, B, entry, ro, rd, rtime, tries);                                           \
       } else {                                                                                                   \
         QuadRecord q;                                                                                            \
         quad_load<(int)sizeof(PathRay), 4>(ray_in, entry, lane, stage, q);                                            \
@@ -1911,7 +1926,8 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_camera_rays(DScene S, uint32_t s
     rng.init(seed_lo, seed_hi, y * S.cam.image_width + x, sy * S.cam.sqrt_spp + sx, CHIP_CAMERA_BOUNCE, 0);
     V3 o, d;
     double time;
-    camera_ray(S.cam, rng, x, y, sx, sy, o, d, time);
+    uint32_t tries = 0;
+    camera_ray(S.cam, rng, x, y, sx, sy, o, d, time, tries);
     double* r = rays + 7 * (size_t)i;
     r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = time;
   }
