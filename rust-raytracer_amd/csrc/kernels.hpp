@@ -21,6 +21,9 @@
 #ifndef CHIP_SHADE_PRIO
 #define CHIP_SHADE_PRIO 1  // wave priority of the shade kernel: its few instructions issue ahead of a co-resident traversal kernel's, so its memory requests leave early
 #endif
+#ifndef CHIP_REFILL_THRESH_B0
+#define CHIP_REFILL_THRESH_B0 48  // the same for camera rays
+#endif
 #ifndef CHIP_REFILL_THRESH
 #define CHIP_REFILL_THRESH 48  // a traversing wave refills its idle lanes once fewer than this many are busy
 #endif
@@ -630,7 +633,7 @@ __device__ inline bool has_zero_component(V3 d) { return !(d.x != 0.0 && d.y != 
 // literally, which the ConstantMedium variant needs (its result depends on the interval it is handed).
 template <uint32_t F, bool YIELD, bool CACHE, bool ORD = true>
 __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng,
-                         TravStack& st, const int base, TravCounters& cnt, bool may_yield = true);
+                         TravStack& st, const int base, TravCounters& cnt, int yield_below = CHIP_REFILL_THRESH);
 
 // A medium's boundary subtree (constant_medium.rs:42-45) is traversed on the same stack; it may hold
 // anything except another medium.
@@ -644,7 +647,7 @@ __device__ __noinline__ void traverse_boundary(const DScene& S, nref_t start, Tr
 
 template <uint32_t F, bool YIELD, bool CACHE, bool ORD>
 __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng,
-                         TravStack& st, const int base, TravCounters& cnt, bool may_yield) {
+                         TravStack& st, const int base, TravCounters& cnt, int yield_below) {
   for (;;) {
     // BVH descent (bvh.rs:58-76): test the node's own box over (tmin, best_t); left first, right deferred.
     if (ORD) {
@@ -830,7 +833,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       if (ORD && hit_medium) r.capf = f32_above(best_t);
     }
     node = st_pop<ORD>(st, base, r.capf);
-    if (YIELD && ORD && may_yield && __popcll(__ballot(1)) < CHIP_REFILL_THRESH) break;  // (the literal form is too heavy to gain from refills)
+    if (YIELD && ORD && __popcll(__ballot(1)) < yield_below) break;  // (the literal form is too heavy to gain from refills)
   }
 #undef CHIP_TAKE
 }
@@ -1519,7 +1522,8 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
     }
     if (!__any(has) && exhausted) break;
     // 3. traverse until the rays are done or too few lanes are still busy
-    if (has) traverse<F, true, CACHE, ORD>(S, C, node, r, 0.001, best_t, best, rng, st, 0, cnt, !(exhausted && w_next >= w_end));
+    if (has) traverse<F, true, CACHE, ORD>(S, C, node, r, 0.001, best_t, best, rng, st, 0, cnt,
+                                           (exhausted && w_next >= w_end) ? 0 : (B0 ? CHIP_REFILL_THRESH_B0 : CHIP_REFILL_THRESH));
   }
   if (st.overflow) atomicOr(&P.errflag[0], 1u);
   // per-wave reduction of the traversal counters
