@@ -22,7 +22,7 @@
 #define CHIP_SHADE_PRIO 1  // wave priority of the shade kernel: its few instructions issue ahead of a co-resident traversal kernel's, so its memory requests leave early
 #endif
 #ifndef CHIP_REFILL_THRESH_B0
-#define CHIP_REFILL_THRESH_B0 48  // the same for camera rays
+#define CHIP_REFILL_THRESH_B0 1  // the same for camera rays: never, so that a wave always computes 64 camera rays at a time
 #endif
 #ifndef CHIP_REFILL_THRESH
 #define CHIP_REFILL_THRESH 48  // a traversing wave refills its idle lanes once fewer than this many are busy
