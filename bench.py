@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # HBM bytes per launch of the traversal kernel on the default workload (1920x1080, 64-strata batches, depth 50),
 # from rocprofv3 PMC passes of this build (2 x FETCH_SIZE + WRITE_SIZE, in KB, summed over the launches of one
 # frame and divided by their number): profiles/r01/pmc_traffic_k_extend.json.  None for any other workload.
-PMC_TRAFFIC_DEFAULT_WORKLOAD = 414.8e6
+PMC_TRAFFIC_DEFAULT_WORKLOAD = 414.0e6
 
 
 def cpu_baseline(width, depth, seed):
