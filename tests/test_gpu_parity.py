@@ -335,3 +335,27 @@ def test_rgb8_quantisation_variants(pkg, gpu, oracle):
     _, a8, _ = sg.render_frame(seed=2, want_rgb8=True)
     _, b8, _ = sg.render_frame(seed=2, want_rgb8=True, flags=pkg.bindings.RENDER_QUANTISE_255)
     assert (a8.astype(int) - b8.astype(int)).min() >= 0 and (a8 != b8).any()
+
+
+def test_full_size_frame_properties(pkg, gpu, monkeypatch):
+    """The benchmark's frame size (1920 x 1080, depth 50; 16 of its 1024 strata so that it runs in a blink), checked
+    through properties that do not need the oracle: batches overlapped on two streams give the bits of the same batches
+    run one after the other, a rectangle is the crop of the frame, and two ranks' strata add up to the frame."""
+    sg = pkg.scenes.build(gpu, "random_spheres", width=1920, spp=16, depth=50)
+    assert sg.image_size() == (1920, 1080)
+    monkeypatch.setenv("CHIP_STREAMS", "1")
+    a, _, sa = sg.render_frame(seed=3, strata_per_batch=4)
+    monkeypatch.delenv("CHIP_STREAMS")
+    b, _, sb = sg.render_frame(seed=3, strata_per_batch=4)
+    assert sa["batches"] == sb["batches"] == 4
+    assert sa["paths"] == sb["paths"] == 1920 * 1080 * 16
+    assert sa["segments"] == sb["segments"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.isfinite(a).all() and a.min() >= 0.0
+    rect = (700, 1500, 300, 900)  # xmin, xmax, ymin, ymax
+    c, _, _ = sg.render_frame(seed=3, rect=rect, strata_per_batch=4)
+    assert np.array_equal(c.view(np.uint32), a[rect[2]:rect[3], rect[0]:rect[1]].view(np.uint32))
+    r0, _, s0 = sg.render_frame(seed=3, stratum_offset=0, stratum_stride=2)
+    r1, _, s1 = sg.render_frame(seed=3, stratum_offset=1, stratum_stride=2)
+    assert s0["segments"] + s1["segments"] == sa["segments"]
+    assert np.allclose(r0 + r1, a, rtol=1e-5, atol=1e-5)
