@@ -804,9 +804,25 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       if (ORD) r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);  // the boundary queries run the literal form
       double t1 = INFINITY, t2 = INFINITY;
       nref_t b1 = NREF_NONE, b2 = NREF_NONE;
-      traverse_boundary<(F & TF_EXT) != 0>(S, m.boundary, r, -INFINITY, t1, b1, rng, st, cnt);
+      if (NREF_KIND(m.boundary) == NK_SPHERE) {
+        // the common boundary, a bare sphere: its two queries (constant_medium.rs:42-45) without the general traversal
+        const DSphere& bs = S.spheres[NREF_INDEX(m.boundary)];
+        double t;
+        cnt.prim++;
+        if (sphere_hit(bs, r, -INFINITY, INFINITY, t)) {
+          t1 = t;
+          b1 = m.boundary;
+          cnt.prim++;
+          if (sphere_hit(bs, r, t1 + 0.0001, INFINITY, t)) {
+            t2 = t;
+            b2 = m.boundary;
+          }
+        }
+      } else {
+        traverse_boundary<(F & TF_EXT) != 0>(S, m.boundary, r, -INFINITY, t1, b1, rng, st, cnt);
+        if (b1 != NREF_NONE) traverse_boundary<(F & TF_EXT) != 0>(S, m.boundary, r, t1 + 0.0001, t2, b2, rng, st, cnt);
+      }
       if (b1 != NREF_NONE) {
-        traverse_boundary<(F & TF_EXT) != 0>(S, m.boundary, r, t1 + 0.0001, t2, b2, rng, st, cnt);
         if (b2 != NREF_NONE) {
           if (t1 < tmin) t1 = tmin;
           if (t2 > best_t) t2 = best_t;
