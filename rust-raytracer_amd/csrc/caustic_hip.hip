@@ -121,7 +121,12 @@ struct chip_scene {
 // Smallest traversal variant that covers the node families present in the flattened scene.
 static uint32_t scene_features(const Flat& F) {
   const uint32_t ext = (!F.discs.empty() || !F.cones.empty() || !F.scales.empty()) ? (TF_QUADS | TF_XFORM | TF_EXT) : 0u;
-  if (!F.media.empty()) return TF_QUADS | TF_XFORM | TF_MEDIA | ext;
+  if (!F.media.empty()) {
+    uint32_t f = TF_QUADS | TF_XFORM | TF_MEDIA | ext;
+    for (const DMedium& m : F.media)
+      if (NREF_KIND(m.boundary) != NK_SPHERE) f |= TF_MEDIA_ANY;
+    return f;
+  }
   if (ext) return ext;
   if (!F.translates.empty() || !F.rotates.empty()) return TF_QUADS | TF_XFORM;
   if (!F.quads.empty() || !F.groups.empty()) return TF_QUADS;
@@ -241,7 +246,7 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
   const char* e = getenv("CHIP_NO_LDS_CACHE");
   p.cache = !uncached && !s->flat.bvh.empty() && !(e && *e == '1');
   if (p.cache) {
-    p.block = (feat & TF_MEDIA) ? 512 : 1024;
+    p.block = (feat & TF_MEDIA_ANY) ? 512 : 1024;
     const bool ordered = true;  // an entry distance is kept beside every stack value
     p.cd.stack_entries = ordered ? 6 : 12;
     if (const char* es = getenv("CHIP_LDS_STACK")) { int v = atoi(es); if (v >= 2 && v <= 16) p.cd.stack_entries = (uint32_t)v; }
@@ -292,7 +297,8 @@ static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat,
     case TF_QUADS | TF_XFORM: CHIP_EXT(TF_QUADS | TF_XFORM); break;
     case TF_QUADS | TF_XFORM | TF_EXT: CHIP_EXT(TF_QUADS | TF_XFORM | TF_EXT); break;
     case TF_QUADS | TF_XFORM | TF_MEDIA: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA); break;
-    default: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT); break;
+    case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY); break;
+    default: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT | TF_MEDIA_ANY); break;
   }
 #undef CHIP_EXT
 }
@@ -1022,8 +1028,9 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
       case TF_QUADS: CHIP_TRACE(TF_QUADS); break;
       case TF_QUADS | TF_XFORM: CHIP_TRACE(TF_QUADS | TF_XFORM); break;
       case TF_QUADS | TF_XFORM | TF_MEDIA: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA); break;
+      case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY); break;
       case TF_QUADS | TF_XFORM | TF_EXT: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_EXT); break;
-      default: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT); break;
+      default: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT | TF_MEDIA_ANY); break;
     }
 #undef CHIP_TRACE
     if ((e = hipGetLastError()) != hipSuccess) break;

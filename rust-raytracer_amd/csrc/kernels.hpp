@@ -582,7 +582,9 @@ __device__ inline void ray_set_inv(TravRay& r) {
 }
 // Scene features a traversal / shade instantiation handles (scenes lacking a feature run a leaner variant):
 // quads & groups | Translate & Rotate | ConstantMedium | discs, cone walls & Scale
-enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4, TF_EXT = 8 };
+// TF_MEDIA_ANY: some medium's boundary is more than a bare sphere (it needs the out-of-line sub-traversal, which
+// costs the whole kernel registers; media bounded by spheres alone run without it)
+enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4, TF_EXT = 8, TF_MEDIA_ANY = 16 };
 
 // translate.rs:28 / rotate.rs:137-138 / scale.rs:97-98
 template <bool EXT>
@@ -804,7 +806,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       if (ORD) r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);  // the boundary queries run the literal form
       double t1 = INFINITY, t2 = INFINITY;
       nref_t b1 = NREF_NONE, b2 = NREF_NONE;
-      if (NREF_KIND(m.boundary) == NK_SPHERE) {
+      if (!(F & TF_MEDIA_ANY) || NREF_KIND(m.boundary) == NK_SPHERE) {
         // the common boundary, a bare sphere: its two queries (constant_medium.rs:42-45) without the general traversal
         const DSphere& bs = S.spheres[NREF_INDEX(m.boundary)];
         double t;
@@ -818,7 +820,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
             b2 = m.boundary;
           }
         }
-      } else {
+      } else if (F & TF_MEDIA_ANY) {
         traverse_boundary<(F & TF_EXT) != 0>(S, m.boundary, r, -INFINITY, t1, b1, rng, st, cnt);
         if (b1 != NREF_NONE) traverse_boundary<(F & TF_EXT) != 0>(S, m.boundary, r, t1 + 0.0001, t2, b2, rng, st, cnt);
       }
@@ -1406,7 +1408,7 @@ struct CacheDesc {
   uint32_t stack_entries;    // per-lane stack entries kept in LDS
 };
 // Threads per block of the traversal kernel: with the LDS scene cache one block owns a whole CU's LDS.
-__host__ __device__ constexpr int extend_block(uint32_t F, bool CACHE) { return CACHE ? ((F & TF_MEDIA) ? 512 : 1024) : CHIP_BLOCK; }
+__host__ __device__ constexpr int extend_block(uint32_t F, bool CACHE) { return CACHE ? ((F & TF_MEDIA_ANY) ? 512 : 1024) : CHIP_BLOCK; }
 // Waves per SIMD the traversal kernel is register-allocated for.  The LDS-cached sphere-scene kernel asks for 6
 // (at most 80 VGPRs) although only 4 of its own waves fit beside its LDS: the registers it leaves free are
 // what lets two shade waves per SIMD of the other batch run next to it.
