@@ -128,7 +128,8 @@ static uint32_t scene_features(const Flat& F) {
     return f;
   }
   if (ext) return ext;
-  if (!F.translates.empty() || !F.rotates.empty()) return TF_QUADS | TF_XFORM;
+  if (!F.translates.empty() || !F.rotates.empty())
+    return TF_QUADS | TF_XFORM | ((F.quads.empty() && F.rotates.empty()) ? TF_NO_QUADROT : 0u);
   if (!F.quads.empty() || !F.groups.empty()) return TF_QUADS;
   return 0;
 }
@@ -295,6 +296,7 @@ static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat,
     case 0: CHIP_EXT(0); break;
     case TF_QUADS: CHIP_EXT(TF_QUADS); break;
     case TF_QUADS | TF_XFORM: CHIP_EXT(TF_QUADS | TF_XFORM); break;
+    case TF_QUADS | TF_XFORM | TF_NO_QUADROT: CHIP_EXT(TF_QUADS | TF_XFORM | TF_NO_QUADROT); break;
     case TF_QUADS | TF_XFORM | TF_EXT: CHIP_EXT(TF_QUADS | TF_XFORM | TF_EXT); break;
     case TF_QUADS | TF_XFORM | TF_MEDIA: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA); break;
     case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY); break;
@@ -1027,6 +1029,7 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
       case 0: CHIP_TRACE(0); break;
       case TF_QUADS: CHIP_TRACE(TF_QUADS); break;
       case TF_QUADS | TF_XFORM: CHIP_TRACE(TF_QUADS | TF_XFORM); break;
+      case TF_QUADS | TF_XFORM | TF_NO_QUADROT: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_NO_QUADROT); break;
       case TF_QUADS | TF_XFORM | TF_MEDIA: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA); break;
       case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY); break;
       case TF_QUADS | TF_XFORM | TF_EXT: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_EXT); break;

@@ -584,7 +584,9 @@ __device__ inline void ray_set_inv(TravRay& r) {
 // quads & groups | Translate & Rotate | ConstantMedium | discs, cone walls & Scale
 // TF_MEDIA_ANY: some medium's boundary is more than a bare sphere (it needs the out-of-line sub-traversal, which
 // costs the whole kernel registers; media bounded by spheres alone run without it)
-enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4, TF_EXT = 8, TF_MEDIA_ANY = 16 };
+// TF_NO_QUADROT (with TF_QUADS | TF_XFORM only): groups and Translates but neither quads nor Rotates, the shape of
+// instanced-sphere scenes (what the OpenSCAD front end emits for spheres: Translate(Group[Sphere]))
+enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4, TF_EXT = 8, TF_MEDIA_ANY = 16, TF_NO_QUADROT = 32 };
 
 // translate.rs:28 / rotate.rs:137-138 / scale.rs:97-98
 template <bool EXT>
@@ -709,7 +711,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       SphereRec sp;
       load_sphere<CACHE>(S, C, idx, sp);
       if (ORD ? sphere_hit_incl(sp, r, tmin, best_t, t) : sphere_hit(sp, r, tmin, best_t, t)) { CHIP_TAKE(node, t, sp.mat) }
-    } else if ((F & TF_QUADS) && kind == NK_QUAD) {
+    } else if ((F & TF_QUADS) && !(F & TF_NO_QUADROT) && kind == NK_QUAD) {
       double t, al, be;
       cnt.prim++;
       if (quad_hit(S.quads[idx], r, tmin, best_t, t, al, be)) { CHIP_TAKE(node, t, S.quads[idx].mat) }
@@ -738,7 +740,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
           if (ORD ? sphere_hit_incl(S.spheres[NREF_INDEX(c)], r, tmin, best_t, t) : sphere_hit(S.spheres[NREF_INDEX(c)], r, tmin, best_t, t)) {
             CHIP_TAKE(c, t, S.spheres[NREF_INDEX(c)].mat)
           }
-        } else if (ck == NK_QUAD) {
+        } else if (!(F & TF_NO_QUADROT) && ck == NK_QUAD) {
           double t, al, be;
           cnt.prim++;
           if (quad_hit(S.quads[NREF_INDEX(c)], r, tmin, best_t, t, al, be)) { CHIP_TAKE(c, t, S.quads[NREF_INDEX(c)].mat) }
@@ -767,7 +769,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       if (ORD) ray_set_cull(r);
       node = t.child;
       continue;
-    } else if ((F & TF_XFORM) && kind == NK_ROTATE) {
+    } else if ((F & TF_XFORM) && !(F & TF_NO_QUADROT) && kind == NK_ROTATE) {
       const DRotate& t = S.rotates[idx];
       st_push<ORD>(st, NREF(NK_EXIT_ROTATE, idx));
       r.o = mat_mulT(t.m, r.o);
