@@ -98,6 +98,8 @@ struct alignas(8) DTranslate {
   nref_t child;
   nref_t parent_xform;             // innermost transform ancestor of this node, or NREF_NONE
   uint32_t chain_first, chain_len;  // this node's root->self transform chain in xchain[]
+  nref_t only_sphere;  // the sphere, when all the Translate holds is one sphere (directly or as a Group's only child); else NREF_NONE
+  uint32_t pad;
 };
 
 struct alignas(8) DRotate {

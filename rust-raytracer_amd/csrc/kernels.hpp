@@ -764,11 +764,25 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       if (descend != NREF_NONE) { node = descend; continue; }
     } else if ((F & TF_XFORM) && kind == NK_TRANSLATE) {
       const DTranslate& t = S.translates[idx];
-      st_push<ORD>(st, NREF(NK_EXIT_TRANSLATE, idx));
-      r.o = r.o - ld3(t.off);
-      if (ORD) ray_set_cull(r);
-      node = t.child;
-      continue;
+      if (t.only_sphere != NREF_NONE) {
+        // A Translate around a single sphere (translate.rs:26-38 over group.rs:44-54 over sphere.rs:99-121): the same
+        // arithmetic on the offset origin, without entering and leaving the instance on the stack.
+        const V3 outer_o = r.o;
+        r.o = r.o - ld3(t.off);
+        const nref_t c = t.only_sphere;
+        double tt;
+        cnt.prim++;
+        if (ORD ? sphere_hit_incl(S.spheres[NREF_INDEX(c)], r, tmin, best_t, tt) : sphere_hit(S.spheres[NREF_INDEX(c)], r, tmin, best_t, tt)) {
+          CHIP_TAKE(c, tt, S.spheres[NREF_INDEX(c)].mat)
+        }
+        r.o = outer_o;
+      } else {
+        st_push<ORD>(st, NREF(NK_EXIT_TRANSLATE, idx));
+        r.o = r.o - ld3(t.off);
+        if (ORD) ray_set_cull(r);
+        node = t.child;
+        continue;
+      }
     } else if ((F & TF_XFORM) && !(F & TF_NO_QUADROT) && kind == NK_ROTATE) {
       const DRotate& t = S.rotates[idx];
       st_push<ORD>(st, NREF(NK_EXIT_ROTATE, idx));

@@ -560,7 +560,15 @@ struct HostScene {
             t.chain_len = (uint32_t)chain.size();
           }
           nref_t c = emit(n.c0, self, in_boundary, leaf_override, tests);
-          if (n.kind == CHIP_NODE_TRANSLATE) F.translates[idx].child = c;
+          if (n.kind == CHIP_NODE_TRANSLATE) {
+            F.translates[idx].child = c;
+            nref_t only = NREF_NONE;
+            if (NREF_KIND(c) == NK_SPHERE) only = c;
+            else if (NREF_KIND(c) == NK_GROUP && F.groups[NREF_INDEX(c)].count == 1 && NREF_KIND(F.gchild[F.groups[NREF_INDEX(c)].first]) == NK_SPHERE)
+              only = F.gchild[F.groups[NREF_INDEX(c)].first];
+            F.translates[idx].only_sphere = only;
+            F.translates[idx].pad = 0;
+          }
           else if (n.kind == CHIP_NODE_ROTATE) F.rotates[idx].child = c;
           else F.scales[idx].child = c;
           return self;
