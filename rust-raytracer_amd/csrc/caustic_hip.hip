@@ -319,8 +319,11 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
   const bool exact_shading = (o->flags & CHIP_RENDER_EXACT_SHADING) != 0;
   const uint32_t feat = scene_features(s->flat);
   // spheres with solid colours and no light sampling: the lean shade kernels
-  bool lean = feat == 0 && !s->flat.has_lights;
-  for (const DTexture& t : s->host.textures) lean = lean && t.kind == TK_SOLID;
+  bool solid_only = !s->flat.has_lights;
+  for (const DTexture& t : s->host.textures) solid_only = solid_only && t.kind == TK_SOLID;
+  const bool lean = feat == 0 && solid_only;
+  // the same under Translate / Rotate instances (instanced spheres, nothing else to intersect)
+  const bool lean_xform = solid_only && (feat & ~TF_NO_QUADROT) == (TF_QUADS | TF_XFORM) && s->flat.quads.empty() && s->flat.media.empty();
 
   // pools: two when the render is large enough to be worth splitting
   const size_t want_total = (size_t)pl.rw * pl.rh * std::max<uint32_t>(pl.s_count, 1);
@@ -448,6 +451,8 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
   } while (0)
         if (lean) {
           if (exact_shading) CHIP_SHADE(false, true, false); else CHIP_SHADE(true, true, false);
+        } else if (lean_xform) {
+          if (exact_shading) CHIP_SHADE(false, true, true); else CHIP_SHADE(true, true, true);
         } else if (ext) {
           if (exact_shading) CHIP_SHADE(false, false, true); else CHIP_SHADE(true, false, true);
         } else {

@@ -1580,7 +1580,8 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
 // scattered, false with the radiance xw that ends the path otherwise; the caller composes either with the
 // path's radiance map, which therefore need not occupy registers here.
 // LEAN is the variant for scenes made only of spheres with solid-colour textures and no lights (no
-// transforms, quads, media, image / noise / checker textures or light sampling to carry in registers).
+// transforms, quads, media, image / noise / checker textures or light sampling to carry in registers);
+// LEAN with EXT is the same for spheres under Translate / Rotate instances.
 template <uint32_t KIND, bool FAST, bool LEAN, bool EXT>
 __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t bounce, uint32_t slot, const PathHit& ph, V3 ro, V3 rd,
                                  double rtime, float (&xw)[3], float& klo_out, float& khi_out, V3& next_o, V3& next_d) {
@@ -1591,7 +1592,7 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
   const DMaterial& M = S.materials[MATK_ID(ph.info)];
   const bool has_lights = !LEAN && S.has_lights;
   HitOut hrec;
-  reconstruct<LEAN ? 0u : (TF_QUADS | TF_XFORM | TF_MEDIA | (EXT ? TF_EXT : 0u)), FAST>(S, leaf, ph.t, ro, rd, rtime, hrec, !LEAN && (M.flags & MF_NEEDS_UV) != 0);
+  reconstruct<LEAN ? (EXT ? TF_XFORM : 0u) : (TF_QUADS | TF_XFORM | TF_MEDIA | (EXT ? TF_EXT : 0u)), FAST>(S, leaf, ph.t, ro, rd, rtime, hrec, !LEAN && (M.flags & MF_NEEDS_UV) != 0);
   const bool front = hrec.front;
   const V3 pt = hrec.pt;
   if (KIND == MK_DIFFUSE_LIGHT) {
