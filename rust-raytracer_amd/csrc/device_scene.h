@@ -99,6 +99,9 @@ struct alignas(8) DTranslate {
   nref_t parent_xform;             // innermost transform ancestor of this node, or NREF_NONE
   uint32_t chain_first, chain_len;  // this node's root->self transform chain in xchain[]
   nref_t only_sphere;  // the sphere, when all the Translate holds is one sphere (directly or as a Group's only child); else NREF_NONE
+  // Where a traversal that enters this node continues: through a run of nested instances (each the other's only
+  // content, e.g. Translate(Rotate(Box))) straight into the innermost one's space (enter_xform) and child.
+  nref_t enter_xform, enter_child;
   uint32_t pad;
 };
 
@@ -107,6 +110,7 @@ struct alignas(8) DRotate {
   nref_t child;
   nref_t parent_xform;
   uint32_t chain_first, chain_len;
+  nref_t enter_xform, enter_child;  // see DTranslate
 };
 
 struct alignas(8) DScale {
@@ -114,6 +118,7 @@ struct alignas(8) DScale {
   nref_t child;
   nref_t parent_xform;
   uint32_t chain_first, chain_len;
+  nref_t enter_xform, enter_child;  // see DTranslate
 };
 
 struct alignas(8) DMedium {

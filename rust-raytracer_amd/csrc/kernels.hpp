@@ -632,6 +632,21 @@ __device__ inline void ray_to_space(const DScene& S, nref_t x, V3 wo, V3 wd, V3&
 // are traced by the literal interpretation instead.
 __device__ inline bool has_zero_component(V3 d) { return !(d.x != 0.0 && d.y != 0.0 && d.z != 0.0) || d.x != d.x || d.y != d.y || d.z != d.z; }
 
+// Takes the ray straight into the space of `inner`, the innermost of a run of nested instances (the instances in
+// between have no effect of their own: translate.rs:26-38, rotate.rs:137-150, scale.rs:93-115 only transform the ray
+// and hand it on).  Returns true when the ordered traversal has to hand the ray back (a zero direction component).
+template <uint32_t F, bool ORD>
+__device__ inline bool enter_instances(const DScene& S, nref_t inner, TravRay& r, TravStack& st) {
+  ray_to_space<(F & TF_EXT) != 0>(S, inner, r.wo, r.wd, r.o, r.d);
+  if (ORD && has_zero_component(r.d)) {
+    st.redo = 1;
+    return true;
+  }
+  ray_set_inv<ORD>(r);
+  return false;
+}
+
+
 // ORD selects the ordered traversal (nearer child first, f32 child-box culling, ties settled by the
 // reference's visiting order); without it the reference's own order and f64 box tests are interpreted
 // literally, which the ConstantMedium variant needs (its result depends on the interval it is handed).
@@ -778,14 +793,27 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
         r.o = outer_o;
       } else {
         st_push<ORD>(st, NREF(NK_EXIT_TRANSLATE, idx));
-        r.o = r.o - ld3(t.off);
-        if (ORD) ray_set_cull(r);
-        node = t.child;
+        if (t.enter_xform == node) {
+          r.o = r.o - ld3(t.off);
+          if (ORD) ray_set_cull(r);
+        } else if (enter_instances<F, ORD>(S, t.enter_xform, r, st)) {
+          node = NREF_NONE;
+          return;
+        }
+        node = t.enter_child;
         continue;
       }
     } else if ((F & TF_XFORM) && !(F & TF_NO_QUADROT) && kind == NK_ROTATE) {
       const DRotate& t = S.rotates[idx];
       st_push<ORD>(st, NREF(NK_EXIT_ROTATE, idx));
+      if (t.enter_xform != node) {
+        if (enter_instances<F, ORD>(S, t.enter_xform, r, st)) {
+          node = NREF_NONE;
+          return;
+        }
+        node = t.enter_child;
+        continue;
+      }
       r.o = mat_mulT(t.m, r.o);
       r.d = mat_mulT(t.m, r.d);
       if (ORD && has_zero_component(r.d)) {  // only an exact cancellation gets here: start over, literally
@@ -799,6 +827,14 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
     } else if ((F & TF_EXT) && kind == NK_SCALE) {
       const DScale& t = S.scales[idx];
       st_push<ORD>(st, NREF(NK_EXIT_SCALE, idx));
+      if (t.enter_xform != node) {
+        if (enter_instances<F, ORD>(S, t.enter_xform, r, st)) {
+          node = NREF_NONE;
+          return;
+        }
+        node = t.enter_child;
+        continue;
+      }
       r.o = mat_mul(t.inv, r.o);
       r.d = mat_mul(t.inv, r.d);
       if (ORD && has_zero_component(r.d)) {  // a zero (or 0 * inf = NaN) component: start over, literally

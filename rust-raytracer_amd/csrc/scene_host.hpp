@@ -571,6 +571,18 @@ struct HostScene {
           }
           else if (n.kind == CHIP_NODE_ROTATE) F.rotates[idx].child = c;
           else F.scales[idx].child = c;
+          // the run of nested instances below this one (stopping before a Translate that is tested in place)
+          nref_t ex = self, ec = c;
+          for (;;) {
+            const uint32_t k = NREF_KIND(ec), i = NREF_INDEX(ec);
+            if (k == NK_TRANSLATE && F.translates[i].only_sphere == NREF_NONE) { ex = ec; ec = F.translates[i].child; }
+            else if (k == NK_ROTATE) { ex = ec; ec = F.rotates[i].child; }
+            else if (k == NK_SCALE) { ex = ec; ec = F.scales[i].child; }
+            else break;
+          }
+          if (n.kind == CHIP_NODE_TRANSLATE) { F.translates[idx].enter_xform = ex; F.translates[idx].enter_child = ec; }
+          else if (n.kind == CHIP_NODE_ROTATE) { F.rotates[idx].enter_xform = ex; F.rotates[idx].enter_child = ec; }
+          else { F.scales[idx].enter_xform = ex; F.scales[idx].enter_child = ec; }
           return self;
         }
         case CHIP_NODE_MEDIUM: {
@@ -671,9 +683,9 @@ struct HostScene {
     F.bvh_is_root.swap(ir);
     F.root = remap(F.root);
     for (nref_t& c : F.gchild) c = remap(c);
-    for (DTranslate& t : F.translates) t.child = remap(t.child);
-    for (DRotate& t : F.rotates) t.child = remap(t.child);
-    for (DScale& t : F.scales) t.child = remap(t.child);
+    for (DTranslate& t : F.translates) { t.child = remap(t.child); t.enter_child = remap(t.enter_child); }
+    for (DRotate& t : F.rotates) { t.child = remap(t.child); t.enter_child = remap(t.enter_child); }
+    for (DScale& t : F.scales) { t.child = remap(t.child); t.enter_child = remap(t.enter_child); }
     for (DMedium& m : F.media) m.boundary = remap(m.boundary);
   }
 
