@@ -61,6 +61,7 @@ struct chip_scene {
   DevBuf<DQuad> d_quads;
   DevBuf<DGroup> d_groups;
   DevBuf<nref_t> d_gchild;
+  DevBuf<float> d_gbox;
   DevBuf<DTranslate> d_translates;
   DevBuf<DRotate> d_rotates;
   DevBuf<DScale> d_scales;
@@ -106,7 +107,7 @@ struct chip_scene {
   uint32_t* h_pinned = nullptr;
 
   void release_device() {
-    d_bvh.release(); d_tnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release();
+    d_bvh.release(); d_tnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release(); d_gbox.release();
     d_translates.release(); d_rotates.release(); d_scales.release(); d_discs.release(); d_cones.release(); d_media.release(); d_xchain.release(); d_materials.release();
     d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
     for (int k = 0; k < kMaxLanes; k++) pools[k].release();
@@ -874,6 +875,7 @@ int chip_commit(chip_scene* s) {
   HIP_TRY(s->d_quads.upload(F.quads));
   HIP_TRY(s->d_groups.upload(F.groups));
   HIP_TRY(s->d_gchild.upload(F.gchild));
+  HIP_TRY(s->d_gbox.upload(F.gbox));
   HIP_TRY(s->d_translates.upload(F.translates));
   HIP_TRY(s->d_rotates.upload(F.rotates));
   HIP_TRY(s->d_scales.upload(F.scales));
@@ -907,7 +909,7 @@ int chip_commit(chip_scene* s) {
   if (F.has_lights && F.lights.empty() && !F.lights_is_group) return fail("internal: empty light list");
   HIP_TRY(s->d_lights.upload(F.lights));
   DScene& D = s->dscene;
-  D.bvh = s->d_bvh.p; D.tnodes = s->d_tnodes.p; D.spheres = s->d_spheres.p; D.quads = s->d_quads.p; D.groups = s->d_groups.p; D.gchild = s->d_gchild.p;
+  D.bvh = s->d_bvh.p; D.tnodes = s->d_tnodes.p; D.spheres = s->d_spheres.p; D.quads = s->d_quads.p; D.groups = s->d_groups.p; D.gchild = s->d_gchild.p; D.gbox = s->d_gbox.p;
   D.translates = s->d_translates.p; D.rotates = s->d_rotates.p; D.scales = s->d_scales.p; D.discs = s->d_discs.p; D.cones = s->d_cones.p;
   D.media = s->d_media.p; D.xchain = s->d_xchain.p;
   D.materials = s->d_materials.p; D.textures = s->d_textures.p; D.perlins = s->d_perlins.p; D.texels = s->d_texels.p;

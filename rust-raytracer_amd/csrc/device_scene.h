@@ -174,6 +174,7 @@ struct DScene {
   const DQuad* quads;
   const DGroup* groups;
   const nref_t* gchild;
+  const float* gbox;  // 6 floats per gchild entry: the child's bounding box rounded outward to f32 (culling only)
   const DTranslate* translates;
   const DRotate* rotates;
   const DScale* scales;

@@ -749,6 +749,13 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       for (; pos < g.count; pos++) {
         nref_t c = S.gchild[g.first + pos];
         uint32_t ck = NREF_KIND(c);
+        if (ORD && !(F & TF_NO_QUADROT) && g.count > 1) {
+          // a child whose box the ray cannot reach before the closest hit so far holds nothing for it (a box's six
+          // quads: at most two can be hit); an only child's box is the group's own, tested on the way here
+          float en, ex;
+          cull_slab(S.gbox + 6u * (g.first + pos), r, en, ex);
+          if (!(en <= ex)) continue;
+        }
         if (ck == NK_SPHERE) {
           double t;
           cnt.prim++;

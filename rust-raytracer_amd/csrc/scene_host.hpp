@@ -92,6 +92,7 @@ struct Flat {
   std::vector<DQuad> quads;
   std::vector<DGroup> groups;
   std::vector<nref_t> gchild;
+  std::vector<float> gbox;  // 6 per gchild entry
   std::vector<DTranslate> translates;
   std::vector<DRotate> rotates;
   std::vector<DScale> scales;
@@ -498,6 +499,13 @@ struct HostScene {
           g.first = (uint32_t)F.gchild.size();
           g.count = (uint32_t)refs.size();
           F.gchild.insert(F.gchild.end(), refs.begin(), refs.end());
+          // The reference's Group tests every child (group.rs:44-54); the ordered traversal first asks the child's
+          // box, in f32 and rounded outward like the culling trees' boxes, whether the ray can reach it at all.
+          for (int k : n.kids) {
+            float b[6];
+            set_cull_box(b, H.nodes[k].box);
+            F.gbox.insert(F.gbox.end(), b, b + 6);
+          }
           F.groups.push_back(g);
           return NREF(NK_GROUP, F.groups.size() - 1);
         }
