@@ -379,6 +379,7 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
     chip_scene::PoolBufs* pb = nullptr;
     hipStream_t st = nullptr;
     bool active = false;
+    bool traced = false;  // all bounces of the batch are enqueued; only the accumulation is still to come
     size_t batch = 0;
     uint32_t bounce = 0, live_upper = 0;
     // live-count readbacks in flight: the host runs ahead of the device and only learns a bounce's live
@@ -412,12 +413,17 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
 
   auto finish_batch = [&](Lane& L) -> int {
     const Batch& bt = batches[L.batch];
-    if (L.batch > 0 && ev_acc[L.batch - 1]) HIP_TRY(hipStreamWaitEvent(L.st, ev_acc[L.batch - 1], 0));
+    // the sums take the batches in order: a batch whose predecessor (on another stream) has not been
+    // enqueued to its end yet waits on the host and is asked again on the next round
+    L.traced = true;
+    if (L.batch > 0 && !ev_acc[L.batch - 1]) return 0;
+    if (L.batch > 0) HIP_TRY(hipStreamWaitEvent(L.st, ev_acc[L.batch - 1], 0));
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(bt.B.npix)), dim3(CHIP_BLOCK), 0, L.st, L.pb->P, bt.B, d_sum + (size_t)bt.by * pl.rw * 3);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventCreateWithFlags(&ev_acc[L.batch], hipEventDisableTiming));
     HIP_TRY(hipEventRecord(ev_acc[L.batch], L.st));
     L.active = false;
+    L.traced = false;
     return 0;
   };
   static const uint32_t shade_grid_max = [] {
@@ -516,7 +522,7 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       any = true;
       rc = poll_readbacks(L, false);
       if (rc) break;
-      if (L.live_upper == 0) rc = finish_batch(L);
+      if (L.traced || L.live_upper == 0) rc = finish_batch(L);
       else rc = advance(L);
       if (rc == 0 && !L.active) {  // the batch is fully enqueued: its readbacks are of no further use
         L.rb_head = 0;

@@ -1897,16 +1897,17 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_ti
 // ascending order per pixel (camera.rs:335-341's `pixel_color += sample`).
 __global__ void __launch_bounds__(CHIP_BLOCK) k_accumulate(PathPool P, BatchDesc B, float* sum_rgb) {
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < B.npix; p += gridDim.x * blockDim.x) {
-    float r = 0.f, g = 0.f, b = 0.f;
+    // the running sums take one sample after the other, so the result does not depend on where the batches were cut
+    float r = sum_rgb[(size_t)p * 3 + 0], g = sum_rgb[(size_t)p * 3 + 1], b = sum_rgb[(size_t)p * 3 + 2];
     for (uint32_t sb = 0; sb < B.n_strata; sb++) {
       const float4 v = P.sample[(size_t)sb * B.npix + p];
       r += v.x;
       g += v.y;
       b += v.z;
     }
-    sum_rgb[(size_t)p * 3 + 0] += r;
-    sum_rgb[(size_t)p * 3 + 1] += g;
-    sum_rgb[(size_t)p * 3 + 2] += b;
+    sum_rgb[(size_t)p * 3 + 0] = r;
+    sum_rgb[(size_t)p * 3 + 1] = g;
+    sum_rgb[(size_t)p * 3 + 2] = b;
   }
 }
 

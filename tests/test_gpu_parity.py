@@ -148,8 +148,9 @@ def test_determinism_and_partition_invariance(pkg, gpu):
     h0, _, _ = sg.render_frame(seed=5, stratum_offset=0, stratum_stride=2)
     h1, _, _ = sg.render_frame(seed=5, stratum_offset=1, stratum_stride=2)
     np.testing.assert_allclose(h0 + h1, a, rtol=2e-6, atol=1e-6)
+    # a pixel's running sum takes its samples one by one in stratum order, wherever the batches are cut
     d, _, _ = sg.render_frame(seed=5, strata_per_batch=3)
-    np.testing.assert_allclose(d, a, rtol=2e-6, atol=1e-6)
+    assert np.array_equal(d.view(np.uint32), a.view(np.uint32))
     w, h = sg.image_size()
     rect = (37, 201, 11, 97)
     r, _, _ = sg.render_frame(seed=5, rect=rect)
@@ -293,7 +294,7 @@ def test_overlapped_batches_equal_single_stream(pkg, gpu, monkeypatch):
     monkeypatch.delenv("CHIP_STREAMS")
     monkeypatch.setenv("CHIP_OVERLAP_MIN_PATHS", "1000")
     b, _, sb = sg.render_frame(seed=9, strata_per_batch=5)
-    assert sa["batches"] == sb["batches"] >= 12
+    assert min(sa["batches"], sb["batches"]) >= 12  # (a smaller pool cuts the overlapped run into more batches)
     assert sa["segments"] == sb["segments"]
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
@@ -347,7 +348,7 @@ def test_full_size_frame_properties(pkg, gpu, monkeypatch):
     a, _, sa = sg.render_frame(seed=3, strata_per_batch=4)
     monkeypatch.delenv("CHIP_STREAMS")
     b, _, sb = sg.render_frame(seed=3, strata_per_batch=4)
-    assert sa["batches"] == sb["batches"] == 4
+    assert min(sa["batches"], sb["batches"]) >= 4
     assert sa["paths"] == sb["paths"] == 1920 * 1080 * 16
     assert sa["segments"] == sb["segments"]
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
