@@ -79,6 +79,31 @@ pub struct chip_stats {
     pub batches: u64,
 }
 
+pub const CHIP_FLAT_MOVING: u32 = 1;
+pub const CHIP_FLAT_MEDIUM_TEX: u32 = 2;
+
+/// One constructor call of `chip_scene_from_flat` (see caustic_hip.h for the meaning of `v` per kind).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct chip_flat_node {
+    pub kind: i32,
+    pub mat: i32,
+    pub first: i32,
+    pub count: i32,
+    pub flags: u32,
+    pub reserved: u32,
+    pub v: [f64; 9],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct chip_flat_scene {
+    pub nodes: *const chip_flat_node,
+    pub n_nodes: usize,
+    pub members: *const i32,
+    pub n_members: usize,
+}
+
 extern "C" {
     pub fn chip_last_error() -> *const c_char;
     pub fn chip_device_count() -> c_int;
@@ -109,6 +134,7 @@ extern "C" {
     pub fn chip_cone_frustum(s: *mut chip_scene, base: *const f64, height: f64, top_radius: f64, bottom_radius: f64, mat: c_int) -> c_int;
     pub fn chip_constant_medium_color(s: *mut chip_scene, boundary: c_int, density: f64, r: f64, g: f64, b: f64) -> c_int;
     pub fn chip_constant_medium_tex(s: *mut chip_scene, boundary: c_int, density: f64, tex: c_int) -> c_int;
+    pub fn chip_scene_from_flat(s: *mut chip_scene, flat: *const chip_flat_scene, node_ids: *mut i32) -> i64;
     pub fn chip_scene_set_world(s: *mut chip_scene, node: c_int) -> c_int;
     pub fn chip_scene_set_lights(s: *mut chip_scene, node: c_int) -> c_int;
     pub fn chip_scene_set_camera(s: *mut chip_scene, desc: *const chip_camera_desc) -> c_int;

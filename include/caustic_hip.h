@@ -152,6 +152,36 @@ int chip_cone_frustum(chip_scene* s, const double base[3], double height, double
 int chip_constant_medium_color(chip_scene* s, int boundary, double density, double r, double g, double b); /* constant_medium.rs:31-37 */
 int chip_constant_medium_tex(chip_scene* s, int boundary, double density, int tex);        /* constant_medium.rs:19-29 */
 
+/* Many nodes in one call, for scenes of 10^5..10^6 objects such as the ones the OpenSCAD front end builds in a loop
+ * (crates/openscad/src/interpreter/modules.rs:76-105 per child; one million Translate(Group[Sphere]) for a 100^3 `for`
+ * nest): record i runs the constructor named by `kind` with the same arguments, in the same order, as the per-node
+ * functions above, so the scene is the one a loop over those functions would have built.
+ *   v[] per kind: SPHERE center[3], radius, (direction[3] with CHIP_FLAT_MOVING) | QUAD q[3], u[3], v[3] |
+ *   BOX a[3], b[3] | TRANSLATE offset[3] | ROTATE axis[3], degrees | SCALE sx, sy, sz | DISC center[3], radius, normal[3] |
+ *   CONE base[3], height, top_radius, bottom_radius | MEDIUM density, (r, g, b unless CHIP_FLAT_MEDIUM_TEX: then `mat`
+ *   is a texture id).
+ * `first` is the child of an instance or medium, or the first entry in `members` of a GROUP / BVH with `count` entries.
+ * A child or member value c >= 0 is record c of this call (c < i); c < 0 is the existing scene node ~c.
+ * node_ids (nullable) receives the node id of every record.  Returns the number of records, < 0 on error
+ * (chip_last_error names the record; nodes made before it stay in the scene). */
+enum { CHIP_FLAT_MOVING = 1, CHIP_FLAT_MEDIUM_TEX = 2 };
+typedef struct chip_flat_node {
+  int32_t kind; /* CHIP_NODE_SPHERE / QUAD / BOX / GROUP / BVH / TRANSLATE / ROTATE / SCALE / DISC / CONE / MEDIUM */
+  int32_t mat;
+  int32_t first;
+  int32_t count;
+  uint32_t flags; /* CHIP_FLAT_* */
+  uint32_t reserved;
+  double v[9];
+} chip_flat_node;
+typedef struct chip_flat_scene {
+  const chip_flat_node* nodes;
+  size_t n_nodes;
+  const int32_t* members;
+  size_t n_members;
+} chip_flat_scene;
+int64_t chip_scene_from_flat(chip_scene* s, const chip_flat_scene* flat, int32_t* node_ids);
+
 /* SceneData, crates/core/src/lib.rs:38-43; lights < 0 = None. */
 int chip_scene_set_world(chip_scene* s, int node);
 int chip_scene_set_lights(chip_scene* s, int node);

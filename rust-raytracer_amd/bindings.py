@@ -102,6 +102,19 @@ class CausticError(RuntimeError):
     pass
 
 
+class FlatScene(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_size_t), ("members", C.c_void_p), ("n_members", C.c_size_t)]
+
+
+# chip_flat_node: one constructor call per record (kind, material, child / member range, flags, scalar arguments)
+FLAT_NODE_DTYPE = np.dtype(
+    [("kind", "<i4"), ("mat", "<i4"), ("first", "<i4"), ("count", "<i4"), ("flags", "<u4"), ("reserved", "<u4"), ("v", "<f8", (9,))]
+)
+assert FLAT_NODE_DTYPE.itemsize == 96
+FLAT_MOVING = 1
+FLAT_MEDIUM_TEX = 2
+
+
 def _vec3(v):
     return (C.c_double * 3)(float(v[0]), float(v[1]), float(v[2]))
 
@@ -178,6 +191,7 @@ class Backend:
             "device_count": (i, []),
             "render_accumulate_device": (i, [p, C.POINTER(RenderOpts), p, p, C.POINTER(Stats)]),
             "resolve_device": (i, [p, p, C.c_size_t, p, p, p]),
+            "scene_from_flat": (C.c_int64, [p, C.POINTER(FlatScene), pi32]),
         }.items():
             if hasattr(self.lib, self.prefix + name):
                 f = self.fn(name)
@@ -328,6 +342,58 @@ class Scene:
 
     def constant_medium_tex(self, boundary, density, tex):
         return self._call("constant_medium_tex", boundary, density, tex)
+
+    def from_flat(self, records: np.ndarray, members=None) -> np.ndarray:
+        """Runs one constructor per record of a FLAT_NODE_DTYPE array in a single library call
+        (`scene_from_flat`); returns the node id of every record."""
+        records = np.ascontiguousarray(records, dtype=FLAT_NODE_DTYPE)
+        members = np.ascontiguousarray(members if members is not None else [], dtype=np.int32)
+        ids = np.empty(records.size, dtype=np.int32)
+        fs = FlatScene(records.ctypes.data, records.size, members.ctypes.data, members.size)
+        self._call("scene_from_flat", C.byref(fs), _ptr(ids, C.c_int32))
+        return ids
+
+    def replay_flat(self, records: np.ndarray, members=None) -> np.ndarray:
+        """The loop over the per-node constructors that `from_flat` is defined to equal."""
+        members = np.asarray(members if members is not None else [], dtype=np.int32)
+        ids = np.full(records.size, -1, dtype=np.int32)
+
+        def ref(c, i):
+            if c < 0:
+                return int(~c)
+            if c >= i:
+                raise CausticError(f"flat record {i} refers to a record that is not before it")
+            return int(ids[c])
+
+        for i, r in enumerate(records):
+            k, v, mat = int(r["kind"]), [float(x) for x in r["v"]], int(r["mat"])
+            if k == NODE_SPHERE:
+                ids[i] = self.sphere(v[0:3], v[3], mat, v[4:7] if int(r["flags"]) & FLAT_MOVING else None)
+            elif k == NODE_QUAD:
+                ids[i] = self.quad(v[0:3], v[3:6], v[6:9], mat)
+            elif k == NODE_BOX:
+                ids[i] = self.box(v[0:3], v[3:6], mat)
+            elif k == NODE_DISC:
+                ids[i] = self.disc(v[0:3], v[3], v[4:7], mat)
+            elif k == NODE_CONE:
+                ids[i] = self.cone_frustum(v[0:3], v[3], v[4], v[5], mat)
+            elif k in (NODE_GROUP, NODE_BVH):
+                m = [ref(int(c), i) for c in members[int(r["first"]) : int(r["first"]) + int(r["count"])]]
+                ids[i] = self.group(m) if k == NODE_GROUP else self.bvh(m)
+            elif k == NODE_TRANSLATE:
+                ids[i] = self.translate(ref(int(r["first"]), i), v[0:3])
+            elif k == NODE_ROTATE:
+                ids[i] = self.rotate(ref(int(r["first"]), i), v[0:3], v[3])
+            elif k == NODE_SCALE:
+                ids[i] = self.scale(ref(int(r["first"]), i), v[0], v[1], v[2])
+            elif k == NODE_MEDIUM:
+                if int(r["flags"]) & FLAT_MEDIUM_TEX:
+                    ids[i] = self.constant_medium_tex(ref(int(r["first"]), i), v[0], mat)
+                else:
+                    ids[i] = self.constant_medium_color(ref(int(r["first"]), i), v[0], v[1], v[2], v[3])
+            else:
+                raise CausticError(f"flat record {i}: kind {k} has no constructor")
+        return ids
 
     # scene data
     def set_world(self, node):

@@ -126,6 +126,7 @@ static uint32_t scene_features(const Flat& F) {
     uint32_t f = TF_QUADS | TF_XFORM | TF_MEDIA | ext;
     for (const DMedium& m : F.media)
       if (NREF_KIND(m.boundary) != NK_SPHERE) f |= TF_MEDIA_ANY;
+    if (ext) f |= TF_MEDIA_ANY;  // media together with discs / cones / Scale: only the variant with everything exists
     return f;
   }
   if (ext) return ext;
@@ -265,6 +266,7 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
   }
   return p;
 }
+static bool g_launch_shape_error = false;
 template <uint32_t F, bool CACHE, bool ORD, bool B0>
 static void launch_extend_b(const chip_scene* s, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
                             uint32_t bounce, uint32_t lit_pass) {
@@ -272,6 +274,10 @@ static void launch_extend_b(const chip_scene* s, const PathPool& P, const Extend
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_extend<F, CACHE, ORD, B0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     attr_set = true;
+  }
+  if (p.block != (uint32_t)extend_block(F, CACHE)) {  // never launch a shape the instantiation was not compiled for
+    g_launch_shape_error = true;
+    return;
   }
   uint32_t blocks = (n_live_upper + p.block - 1) / p.block;
   uint32_t max_blocks = CACHE ? (uint32_t)s->n_cus : kMaxGridBlocksDef;
@@ -287,6 +293,18 @@ static void launch_extend_t(const chip_scene* s, const PathPool& P, const Extend
 // One bounce of traversal: the ordered traversal followed by a literal pass over the rays it handed back (normally none; all of
 // them in a reference_order render).
 static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce) {
+  // the launch shape (threads per block, LDS split) must be planned for the instantiation that runs, which for a
+  // feature set without a variant of its own is the one with every feature
+  switch (feat) {
+    case 0:
+    case TF_QUADS:
+    case TF_QUADS | TF_XFORM:
+    case TF_QUADS | TF_XFORM | TF_NO_QUADROT:
+    case TF_QUADS | TF_XFORM | TF_EXT:
+    case TF_QUADS | TF_XFORM | TF_MEDIA:
+    case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: break;
+    default: feat = TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT | TF_MEDIA_ANY; break;
+  }
   const ExtendPlan lit = plan_extend(s, feat, true);
   const ExtendPlan p = plan_extend(s, feat, false);
 #define CHIP_EXT(FEAT)                                                                                             \
@@ -369,7 +387,7 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       B.n_paths = npix * B.n_strata;
       B.seed_lo = (uint32_t)o->seed;
       B.seed_hi = (uint32_t)(o->seed >> 32);
-      B.reference_order = (o->flags & CHIP_RENDER_REFERENCE_ORDER) ? 1u : 0u;
+      B.reference_order = ((o->flags & CHIP_RENDER_REFERENCE_ORDER) || s->dscene.literal_only) ? 1u : 0u;
       bt.by = by;
       batches.push_back(bt);
     }
@@ -447,6 +465,7 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       const uint32_t grid = std::min(grid_for(L.live_upper), shade_grid_max);
       if (time_kernels) (void)hipEventRecord(new_event(), L.st);
       launch_extend(s, P, feat, L.live_upper, L.st, B, bounce);
+      if (g_launch_shape_error) return fail("internal: traversal launch planned for another kernel variant");
       if (time_kernels) (void)hipEventRecord(new_event(), L.st);
       n_trace_launches++;
       {
@@ -835,6 +854,76 @@ int chip_constant_medium_tex(chip_scene* s, int boundary, double density, int te
   return s->host.nodes[s->host.make_medium(s->host.handle[boundary], density, m)].id;
 }
 
+int64_t chip_scene_from_flat(chip_scene* s, const chip_flat_scene* flat, int32_t* node_ids) {
+  NEED_SCENE;
+  if (!flat || (flat->n_nodes && !flat->nodes) || (flat->n_members && !flat->members)) return fail("null argument");
+  if (flat->n_nodes > (size_t)INT32_MAX) return fail("too many records");
+  std::vector<int32_t> made(flat->n_nodes, -1);
+  std::vector<int32_t> group;
+  char msg[160];
+  for (size_t i = 0; i < flat->n_nodes; i++) {
+    const chip_flat_node& R = flat->nodes[i];
+    bool bad_ref = false;
+    auto resolve = [&](int32_t c) -> int32_t {
+      if (c < 0) return ~c;
+      if ((size_t)c >= i) {
+        bad_ref = true;
+        return -1;
+      }
+      return made[(size_t)c];
+    };
+    int id = -1;
+    switch (R.kind) {
+      case CHIP_NODE_SPHERE:
+        id = chip_sphere(s, R.v, R.v[3], R.mat);
+        if (id >= 0 && (R.flags & CHIP_FLAT_MOVING) && chip_sphere_set_direction(s, id, R.v + 4) < 0) id = -1;
+        break;
+      case CHIP_NODE_QUAD: id = chip_quad(s, R.v, R.v + 3, R.v + 6, R.mat); break;
+      case CHIP_NODE_BOX: id = chip_box(s, R.v, R.v + 3, R.mat); break;
+      case CHIP_NODE_DISC: id = chip_disc(s, R.v, R.v[3], R.v + 4, R.mat); break;
+      case CHIP_NODE_CONE: id = chip_cone_frustum(s, R.v, R.v[3], R.v[4], R.v[5], R.mat); break;
+      case CHIP_NODE_GROUP:
+      case CHIP_NODE_BVH: {
+        if (R.first < 0 || R.count < 0 || (size_t)R.first + (size_t)R.count > flat->n_members) {
+          snprintf(msg, sizeof msg, "flat record %zu: member range outside the member list", i);
+          return fail(msg);
+        }
+        group.resize((size_t)R.count);
+        for (int32_t j = 0; j < R.count; j++) group[(size_t)j] = resolve(flat->members[(size_t)R.first + (size_t)j]);
+        if (!bad_ref) id = R.kind == CHIP_NODE_GROUP ? chip_group(s, group.data(), R.count) : chip_bvh(s, group.data(), R.count);
+        break;
+      }
+      case CHIP_NODE_TRANSLATE:
+      case CHIP_NODE_ROTATE:
+      case CHIP_NODE_SCALE:
+      case CHIP_NODE_MEDIUM: {
+        const int32_t child = resolve(R.first);
+        if (bad_ref) break;
+        if (R.kind == CHIP_NODE_TRANSLATE) id = chip_translate(s, child, R.v);
+        else if (R.kind == CHIP_NODE_ROTATE) id = chip_rotate(s, child, R.v, R.v[3]);
+        else if (R.kind == CHIP_NODE_SCALE) id = chip_scale(s, child, R.v[0], R.v[1], R.v[2]);
+        else if (R.flags & CHIP_FLAT_MEDIUM_TEX) id = chip_constant_medium_tex(s, child, R.v[0], R.mat);
+        else id = chip_constant_medium_color(s, child, R.v[0], R.v[1], R.v[2], R.v[3]);
+        break;
+      }
+      default:
+        snprintf(msg, sizeof msg, "flat record %zu: kind %d has no constructor", i, (int)R.kind);
+        return fail(msg);
+    }
+    if (bad_ref) {
+      snprintf(msg, sizeof msg, "flat record %zu refers to a record that is not before it", i);
+      return fail(msg);
+    }
+    if (id < 0) {
+      snprintf(msg, sizeof msg, "flat record %zu: %s", i, chip_last_error());
+      return fail(msg);
+    }
+    made[i] = id;
+  }
+  if (node_ids) std::copy(made.begin(), made.end(), node_ids);
+  return (int64_t)flat->n_nodes;
+}
+
 int chip_scene_set_world(chip_scene* s, int node) {
   NEED_SCENE;
   CHECK_NODE(node);
@@ -924,6 +1013,7 @@ int chip_commit(chip_scene* s) {
   D.n_lights = (uint32_t)F.lights.size();
   D.has_lights = F.has_lights;
   D.lights_is_group = F.lights_is_group;
+  D.literal_only = F.loose_geometry;
   D.cam = s->host.cam;
   s->flat = std::move(F);
   s->committed = true;

@@ -191,5 +191,9 @@ struct DScene {
   uint32_t n_lights;
   uint32_t has_lights;       // SceneData.lights is Some
   uint32_t lights_is_group;  // lights root is a Group (one member is picked per sample)
+  // Some primitive reaches outside its own bounding box (a Disc whose normal is tilted but has a component above 0.9,
+  // disc.rs:25-35): the reference then finds it through whichever enclosing boxes the ray happens to cross, so every
+  // ray replays the reference's visiting order instead of culling by child boxes.
+  uint32_t literal_only;
   DCamera cam;
 };

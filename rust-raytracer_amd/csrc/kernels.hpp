@@ -1952,7 +1952,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P,
     r.time = tm ? tm[i] : 0.0;
     r.o = r.wo; r.d = r.wd;
     constexpr bool ORD = true;
-    bool literal = !ORD || has_zero_component(r.wd);
+    bool literal = !ORD || S.literal_only || has_zero_component(r.wd);
     if (literal) ray_set_inv<false>(r);
     else ray_set_inv<true>(r);
     r.capf = INFINITY;

@@ -103,6 +103,7 @@ struct Flat {
   std::vector<DLight> lights;
   nref_t root = NREF_NONE;
   uint32_t has_lights = 0, lights_is_group = 0;
+  uint32_t loose_geometry = 0;  // some primitive of the world is not bounded by its own box
 };
 
 struct HostScene {
@@ -459,6 +460,15 @@ struct HostScene {
       d.xform = xform;
       d.leaf_id = leaf_id;
       d.seq = seq++;
+      // Disc::new sizes the box as if the normal were along an axis whenever a component exceeds 0.9
+      // (disc.rs:25-35); a tilted disc then sticks out of it
+      {
+        const double len2 = n.a[3] * n.a[3] + n.a[4] * n.a[4] + n.a[5] * n.a[5];
+        for (int i = 0; i < 3 && len2 > 0.0; i++) {
+          const double reach = d.r * std::sqrt(std::fmax(0.0, 1.0 - n.a[3 + i] * n.a[3 + i] / len2));
+          if (n.a[i] - reach < n.box.v[2 * i] || n.a[i] + reach > n.box.v[2 * i + 1]) F.loose_geometry = 1;
+        }
+      }
       F.discs.push_back(d);
       return NREF(NK_DISC, F.discs.size() - 1);
     }

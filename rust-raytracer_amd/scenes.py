@@ -425,7 +425,7 @@ def scad_shapes_cone_light(sc, **kw):
     return scad_shapes(sc, light="cone", **kw)
 
 
-def scad_lattice(sc, n=100, width=None, spp=None, depth=None, seed=1):
+def scad_lattice(sc, n=100, width=None, spp=None, depth=None, seed=1, bulk=None):
     """Synthetic scene with the shape crates/openscad's interpreter emits for nested `for` loops of
     `translate() sphere()` (crates/openscad/src/interpreter/modules.rs:139-163,274; mod.rs:190-194):
     one top-level BVH over n^3 `Translate(Group[Sphere at origin])` chains plus a ground sphere, no lights.
@@ -436,7 +436,46 @@ def scad_lattice(sc, n=100, width=None, spp=None, depth=None, seed=1):
     world = [sc.sphere((0.0, -1000.5, 0.0), 1000.0, sc.lambertian_color(0.5, 0.5, 0.5))]
     idx = 0
     half = n / 2.0
-    for i in range(n):
+    if bulk is None:
+        bulk = hasattr(sc.be.lib, sc.be.prefix + "scene_from_flat")
+    if bulk:
+        # the same nodes in the same creation order, handed over in one call
+        from . import bindings as B
+
+        mats = np.empty(total, dtype=np.int32)
+        for e in range(total):
+            r = u[e]
+            if r[1] < 0.8:
+                mats[e] = sc.lambertian_color(r[2] * r[3], r[3] * r[4], r[4] * r[5])
+            elif r[1] < 0.95:
+                mats[e] = sc.metal(0.5 + 0.5 * r[2], 0.5 + 0.5 * r[3], 0.5 + 0.5 * r[4], 0.5 * r[5])
+            else:
+                mats[e] = sc.dielectric(1.5)
+        rec = np.zeros(3 * total + 1, dtype=B.FLAT_NODE_DTYPE)
+        e = np.arange(total)
+        sph, grp, tr = rec[0:-1:3], rec[1:-1:3], rec[2:-1:3]
+        sph["kind"] = B.NODE_SPHERE
+        sph["mat"] = mats
+        sph["v"][:, 3] = 0.2 + 0.25 * u[:, 0]
+        grp["kind"] = B.NODE_GROUP
+        grp["first"] = e
+        grp["count"] = 1
+        tr["kind"] = B.NODE_TRANSLATE
+        tr["first"] = 3 * e + 1
+        i3, j3, k3 = e // (n * n), (e // n) % n, e % n
+        tr["v"][:, 0] = i3 - half + 0.5
+        tr["v"][:, 1] = j3 + 0.5
+        tr["v"][:, 2] = k3 - half + 0.5
+        members = np.concatenate([3 * e, [~np.int32(world[0])], 3 * e + 2]).astype(np.int32)
+        rec[-1]["kind"] = B.NODE_BVH
+        rec[-1]["first"] = total
+        rec[-1]["count"] = total + 1
+        ids = sc.from_flat(rec, members)
+        sc.set_world(int(ids[-1]))
+        n_iter = 0
+    else:
+        n_iter = n
+    for i in range(n_iter):
         for j in range(n):
             for k in range(n):
                 r = u[idx]
@@ -451,7 +490,8 @@ def scad_lattice(sc, n=100, width=None, spp=None, depth=None, seed=1):
                 g = sc.group([s])
                 world.append(sc.translate(g, (i - half + 0.5, j + 0.5, k - half + 0.5)))
                 idx += 1
-    sc.set_world(sc.bvh(world))
+    if not bulk:
+        sc.set_world(sc.bvh(world))
     sc.set_lights(None)
     d = 1.6 * n
     _camera(
