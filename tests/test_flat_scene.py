@@ -142,3 +142,55 @@ def test_lattice_bulk_equals_loop(pkg, gpu, oracle):
     b, _, sb = sl.render_frame(seed=4)
     assert sa["segments"] == sb["segments"]
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_media_with_general_boundaries_beside_extended_nodes(pkg, gpu, oracle):
+    """Media whose boundaries need the general sub-traversal (an ellipsoid = Scale(Sphere), a rotated box, a cone
+    frustum) in a scene that also holds discs: hits and a same-seed render against the oracle."""
+    B = pkg.bindings
+
+    def build(be):
+        sc = be.new_scene()
+        grey = sc.lambertian_color(0.6, 0.6, 0.6)
+        steel = sc.metal(0.8, 0.8, 0.9, 0.05)
+        glass = sc.dielectric(1.5)
+        ground = sc.sphere((0.0, -1000.0, 0.0), 1000.0, grey)
+        ellipsoid = sc.translate(sc.scale(sc.sphere((0.0, 0.0, 0.0), 1.0, glass), 1.6, 0.8, 1.0), (-2.5, 0.9, 0.0))
+        box = sc.translate(sc.rotate_y(sc.box((-0.7, 0.0, -0.7), (0.7, 1.4, 0.7), grey), 25.0), (0.0, 0.0, 1.0))
+        cone = sc.translate(sc.cone_frustum((0.0, 0.0, 0.0), 1.5, 0.2, 0.9, grey), (2.6, 0.0, -0.5))
+        world = [
+            ground,
+            sc.constant_medium_color(ellipsoid, 0.9, 0.9, 0.5, 0.2),
+            sc.constant_medium_color(box, 1.5, 0.2, 0.4, 0.9),
+            sc.constant_medium_color(cone, 2.5, 0.9, 0.9, 0.9),
+            sc.translate(sc.disc((0.0, 0.0, 0.0), 0.9, (0.0, 1.0, 0.0), steel), (0.5, 2.4, -1.5)),
+            sc.sphere((-0.8, 0.5, 2.6), 0.5, steel),
+        ]
+        sc.set_world(sc.bvh(world))
+        sc.set_lights(None)
+        sc.set_camera(image_width=96, aspect_ratio=1.5, samples_per_pixel=16, max_depth=12, vertical_fov=35, look_from=(2.0, 3.0, 10.0),
+                      look_at=(0.0, 0.8, 0.0), background=(0.7, 0.8, 1.0))
+        sc.commit()
+        return sc
+
+    sg, so = build(gpu), build(oracle)
+    for a, b in zip(sg.dump_tree(), so.dump_tree()):
+        assert np.array_equal(a, b)
+    rng = np.random.default_rng(8)
+    n = 20000
+    o = np.tile(np.array([2.0, 3.0, 10.0]), (n, 1)) + rng.normal(0, 0.3, (n, 3))
+    d = np.array([0.0, 0.8, 0.0]) + rng.uniform(-4, 4, (n, 3)) - o
+    hg, ho = sg.trace_rays(o, d, None, seed=3), so.trace_rays(o, d, None, seed=3)
+    info = compare_hits(hg, ho)
+    assert info["n_hit"] > n // 4
+    assert (hg["material_kind"] == 4).sum() > 200  # Isotropic: rays that scattered inside a medium
+    e, _, se = sg.render_frame(seed=2, flags=B.RENDER_EXACT_SHADING)
+    o_img, _, so_st = so.render_frame(seed=2, sum_dtype=np.float64)
+    assert se["segments"] == so_st["segments"]
+    diff = np.abs(e.astype(np.float64) - o_img)
+    assert (diff > 1e-3 * (1.0 + np.abs(o_img))).mean() < 2e-3
+    a, _, sa = sg.render_frame(seed=2)
+    b, _, sb = sg.render_frame(seed=2, flags=B.RENDER_REFERENCE_ORDER)
+    assert sa["segments"] == sb["segments"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -274,7 +274,7 @@ def test_exact_ties_follow_reference_order(gpu, oracle, variant):
     assert info["n_hit"] > 0.1 * len(o) and info["t_bit_identical"]
 
 
-@pytest.mark.parametrize("name", ["random_spheres", "cornell_box", "final"])
+@pytest.mark.parametrize("name", ["random_spheres", "cornell_box", "final", "cornell_box_smoke", "scad_shapes"])
 def test_ordered_traversal_equals_reference_order_render(pkg, gpu, name):
     """The default ordered traversal and the literal replay of the reference's visiting order find the
     same (t, primitive) for every segment, so whole renders are bit-identical."""
