@@ -776,8 +776,13 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
           if (cone_hit(S.cones[NREF_INDEX(c)], r, tmin, best_t, t)) { CHIP_TAKE(c, t, S.cones[NREF_INDEX(c)].mat) }
         } else {
           if (pos + 1 < g.count) {
-            st_push<ORD>(st, pos + 1);
-            st_push<ORD>(st, NREF(NK_GROUP_CONT, idx));
+            // both words or neither: a marker without its position (or the reverse) would be misread when popped
+            if (st.sp + 2 <= st.lds_cap + CHIP_STACK_OVF) {
+              st_push<ORD>(st, pos + 1);
+              st_push<ORD>(st, NREF(NK_GROUP_CONT, idx));
+            } else {
+              st.overflow = 1;
+            }
           }
           descend = c;
           break;

@@ -194,3 +194,59 @@ def test_media_with_general_boundaries_beside_extended_nodes(pkg, gpu, oracle):
     b, _, sb = sg.render_frame(seed=2, flags=B.RENDER_REFERENCE_ORDER)
     assert sa["segments"] == sb["segments"]
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def nested_groups(sc, depth, width=64):
+    """Group[Group[...[Sphere, Sphere]..., Sphere], Sphere]: every level leaves a continuation on the traversal stack."""
+    mat = sc.lambertian_color(0.7, 0.4, 0.3)
+    node = sc.sphere((0.0, 0.5, 0.0), 0.5, mat)
+    for i in range(depth):
+        s = sc.sphere((0.45 * (i + 1) * (-1) ** i, 0.4, -0.3 * i), 0.4, sc.metal(0.8, 0.8, 0.8, 0.0) if i % 3 == 0 else mat)
+        node = sc.group([node, s])
+    ground = sc.sphere((0.0, -1000.0, 0.0), 1000.0, sc.lambertian_color(0.5, 0.5, 0.5))
+    sc.set_world(sc.bvh([ground, node]))
+    sc.set_lights(None)
+    sc.set_camera(image_width=width, aspect_ratio=1.5, samples_per_pixel=16, max_depth=8, vertical_fov=50, look_from=(0.0, 3.0, 12.0),
+                  look_at=(0.0, 0.5, -2.0), background=(0.7, 0.8, 1.0))
+    sc.commit()
+    return sc
+
+
+@pytest.mark.gpu
+def test_deep_nesting_spills_the_traversal_stack_and_still_matches(pkg, gpu, oracle):
+    """20 nested groups need 40 stack entries: more than the per-lane LDS part of the stack in every kernel variant,
+    so the spill slab in device memory is exercised; results must not change."""
+    B = pkg.bindings
+    sg, so = nested_groups(gpu.new_scene(), 20), nested_groups(oracle.new_scene(), 20)
+    rng = np.random.default_rng(2)
+    n = 20000
+    o = np.tile(np.array([0.0, 3.0, 12.0]), (n, 1))
+    d = np.array([0.0, 0.5, -2.0]) + rng.uniform(-6, 6, (n, 3)) * np.array([1.5, 0.5, 1.0]) - o
+    info = compare_hits(sg.trace_rays(o, d, None, seed=1), so.trace_rays(o, d, None, seed=1))
+    assert info["n_hit"] > n // 4
+    e, _, se = sg.render_frame(seed=2, flags=B.RENDER_EXACT_SHADING)
+    o_img, _, so_st = so.render_frame(seed=2, sum_dtype=np.float64)
+    assert se["segments"] == so_st["segments"]
+    diff = np.abs(e.astype(np.float64) - o_img)
+    assert (diff > 1e-3 * (1.0 + np.abs(o_img))).mean() < 2e-3
+    a, _, sa = sg.render_frame(seed=2)
+    b, _, sb = sg.render_frame(seed=2, flags=B.RENDER_REFERENCE_ORDER)
+    assert sa["segments"] == sb["segments"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_nesting_deeper_than_the_device_stack_is_an_error(pkg, gpu):
+    """40 nested groups need 80 entries, more than any variant's stack: the calls fail with a message instead of
+    returning an image with missing objects."""
+    sg = nested_groups(gpu.new_scene(), 40)
+    o = np.array([[0.0, 3.0, 12.0]] * 64)
+    d = np.array([[0.0, -2.5, -14.0]] * 64)
+    with pytest.raises(pkg.CausticError, match="stack overflow"):
+        sg.trace_rays(o, d, None, seed=1)
+    with pytest.raises(pkg.CausticError, match="stack overflow"):
+        sg.render_frame(seed=1)
+    # the scene handle stays usable
+    ok = nested_groups(gpu.new_scene(), 3)
+    img, _, st = ok.render_frame(seed=1)
+    assert np.isfinite(img).all() and st["paths"] > 0
