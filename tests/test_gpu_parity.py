@@ -360,3 +360,49 @@ def test_full_size_frame_properties(pkg, gpu, monkeypatch):
     r1, _, s1 = sg.render_frame(seed=3, stratum_offset=1, stratum_stride=2)
     assert s0["segments"] + s1["segments"] == sa["segments"]
     assert np.allclose(r0 + r1, a, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("variant", ["bare_quad", "bare_sphere", "empty_group", "group_with_unsampled_members", "disc", "frustum"])
+def test_light_list_shapes(pkg, gpu, oracle, variant):
+    """SceneData.lights in every shape camera.rs:278-305 can meet: a node that is not a Group (its own pdf_value /
+    random), an empty Group (group.rs:60-78: pdf 0, direction (0,1,0)), a Group with members that keep the Node
+    defaults (object/mod.rs:59-65: pdf 0, direction (1,0,0)), a Disc, a ConeFrustum.  Same-seed render against the
+    oracle with the reference's f64 operation order."""
+    def build(be):
+        sc = be.new_scene()
+        white = sc.lambertian_color(0.73, 0.73, 0.73)
+        red = sc.lambertian_color(0.65, 0.05, 0.05)
+        light = sc.diffuse_light_color(15.0, 15.0, 15.0)
+        glass = sc.dielectric(1.5)
+        lq = sc.quad((3.0, 5.0, -1.0), (-2.0, 0.0, 0.0), (0.0, 0.0, -2.0), light)
+        ld = sc.disc((-2.5, 4.0, -2.0), 0.8, (0.0, -1.0, 0.0), light)
+        gs = sc.sphere((0.0, 1.0, -2.0), 1.0, glass)
+        box = sc.box((-3.5, 0.0, -4.0), (-2.0, 2.0, -2.5), white)
+        ts = sc.translate(sc.sphere((0.0, 0.0, 0.0), 0.6, red), (2.5, 0.6, -1.0))
+        cone = sc.cone_frustum((2.5, 3.0, -3.5), 1.0, 0.3, 0.7, light)
+        world = [sc.quad((-6.0, 0.0, -6.0), (12.0, 0.0, 0.0), (0.0, 0.0, 8.0), white), sc.quad((-6.0, 0.0, -6.0), (12.0, 0.0, 0.0), (0.0, 8.0, 0.0), red),
+                 lq, ld, gs, box, ts, cone]
+        sc.set_world(sc.bvh(world))
+        lights = {
+            "bare_quad": lambda: lq,
+            "bare_sphere": lambda: gs,
+            "empty_group": lambda: sc.group([]),
+            "group_with_unsampled_members": lambda: sc.group([lq, box, ts]),
+            "disc": lambda: sc.group([ld, lq]),
+            "frustum": lambda: cone,
+        }[variant]()
+        sc.set_lights(lights)
+        sc.set_camera(image_width=64, aspect_ratio=1.5, samples_per_pixel=36, max_depth=8, vertical_fov=45, look_from=(0.0, 3.0, 9.0),
+                      look_at=(0.0, 1.5, -2.0), background=(0.02, 0.02, 0.03))
+        sc.commit()
+        return sc
+
+    sg, so = build(gpu), build(oracle)
+    img_g, _, st_g = sg.render_frame(seed=6, flags=pkg.bindings.RENDER_EXACT_SHADING)
+    img_o, _, st_o = so.render_frame(seed=6, sum_dtype=np.float64)
+    assert st_g["segments"] == st_o["segments"]
+    diff = np.abs(img_g.astype(np.float64) - img_o)
+    assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
+    assert img_o.mean() > 0.0
+    fast, _, _ = sg.render_frame(seed=6)
+    assert (np.abs(fast.astype(np.float64) - img_o) > 2e-3 * (1.0 + np.abs(img_o))).mean() < 1e-2
