@@ -406,3 +406,22 @@ def test_light_list_shapes(pkg, gpu, oracle, variant):
     assert img_o.mean() > 0.0
     fast, _, _ = sg.render_frame(seed=6)
     assert (np.abs(fast.astype(np.float64) - img_o) > 2e-3 * (1.0 + np.abs(img_o))).mean() < 1e-2
+
+
+def test_small_pool_row_bands_and_streams_give_the_same_bits(pkg, gpu, monkeypatch):
+    """A path pool far smaller than one stratum of the frame: the frame is cut into bands of rows and the strata into
+    many batches, run on one, two or three streams.  The sums are bit-identical to the single-batch render."""
+    kw = dict(width=480, spp=16, depth=50)
+    a, _, sa = pkg.scenes.build(gpu, "random_spheres", **kw).render_frame(seed=5)
+    assert sa["batches"] == 1
+    monkeypatch.setenv("CHIP_POOL_PATHS", "65536")
+    monkeypatch.setenv("CHIP_OVERLAP_MIN_PATHS", "1000")
+    sc = pkg.scenes.build(gpu, "random_spheres", **kw)  # a new scene: pools are sized on first use
+    for streams in ("1", "2", "3"):
+        monkeypatch.setenv("CHIP_STREAMS", streams)
+        b, _, sb = sc.render_frame(seed=5)
+        assert sb["batches"] >= 32 and sb["paths"] == sa["paths"] and sb["segments"] == sa["segments"]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), streams
+    rect = (37, 201, 11, 197)
+    r, _, _ = sc.render_frame(seed=5, rect=rect)
+    assert np.array_equal(r.view(np.uint32), a[rect[2] : rect[3], rect[0] : rect[1]].view(np.uint32))
