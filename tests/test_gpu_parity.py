@@ -412,6 +412,7 @@ def test_small_pool_row_bands_and_streams_give_the_same_bits(pkg, gpu, monkeypat
     """A path pool far smaller than one stratum of the frame: the frame is cut into bands of rows and the strata into
     many batches, run on one, two or three streams.  The sums are bit-identical to the single-batch render."""
     kw = dict(width=480, spp=16, depth=50)
+    monkeypatch.delenv("CHIP_POOL_PATHS", raising=False)
     a, _, sa = pkg.scenes.build(gpu, "random_spheres", **kw).render_frame(seed=5)
     assert sa["batches"] == 1
     monkeypatch.setenv("CHIP_POOL_PATHS", "65536")
