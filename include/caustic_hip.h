@@ -215,8 +215,9 @@ int chip_resolve_device_flags(chip_scene* s, const float* d_sum_rgb, size_t npix
                               void* stream);
 
 /* Test hooks.  chip_trace_rays: closest hit of world over [0.001, inf) (camera.rs:264) for n host
- * rays (origin, direction: n x 3 doubles; time: n doubles or NULL = 0).  Medium free-flight draws
- * use the Philox stream keyed (seed, ray index, 0, bounce 0). */
+ * rays (origin, direction: n x 3 doubles; time: n doubles or NULL = 0; any time is accepted, also outside
+ * the [0, 1) the camera draws, ray.rs / camera.rs:371).  Medium free-flight draws use the Philox stream keyed
+ * (seed, ray index, 0, bounce 0). */
 int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* origin, const double* direction, const double* time,
                     chip_hit* out);
 /* Camera rays of camera.rs:359-374 for n (x, y, s_x, s_y) tuples; rays = n x 7 doubles. */

@@ -1957,7 +1957,9 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P,
     r.time = tm ? tm[i] : 0.0;
     r.o = r.wo; r.d = r.wd;
     constexpr bool ORD = true;
-    bool literal = !ORD || S.literal_only || has_zero_component(r.wd);
+    // a moving sphere's box covers times 0..1 (sphere.rs:36-47); outside of them it leaves its box, and only the
+    // reference's own visiting order says what such a ray finds
+    bool literal = !ORD || S.literal_only || has_zero_component(r.wd) || !(r.time >= 0.0 && r.time <= 1.0);
     if (literal) ray_set_inv<false>(r);
     else ray_set_inv<true>(r);
     r.capf = INFINITY;

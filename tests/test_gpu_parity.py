@@ -426,3 +426,21 @@ def test_small_pool_row_bands_and_streams_give_the_same_bits(pkg, gpu, monkeypat
     rect = (37, 201, 11, 197)
     r, _, _ = sc.render_frame(seed=5, rect=rect)
     assert np.array_equal(r.view(np.uint32), a[rect[2] : rect[3], rect[0] : rect[1]].view(np.uint32))
+
+
+def test_ray_times_outside_the_shutter_interval(pkg, gpu, oracle):
+    """Moving spheres leave their bounding boxes for ray times outside [0, 1] (the boxes cover the motion over that
+    interval only, sphere.rs:36-47); `trace_rays` accepts any time and must still answer as the reference would."""
+    sg, so = build_pair(pkg, gpu, oracle, "random_spheres", width=64, spp=4, depth=4)
+    rng = np.random.default_rng(3)
+    n = 100_000
+    o = np.array([13.0, 2.0, 3.0]) + rng.normal(0.0, 0.2, (n, 3))
+    target = np.stack([rng.uniform(-11, 11, n), rng.uniform(-1.5, 2.5, n), rng.uniform(-11, 11, n)], axis=1)
+    d = target - o
+    t = rng.uniform(-3.0, 4.0, n)
+    hg, ho = sg.trace_rays(o, d, t, seed=1), so.trace_rays(o, d, t, seed=1)
+    info = compare_hits(hg, ho)
+    assert info["n_hit"] > n // 4
+    # some of these hits are on spheres that have left their boxes: their centres lie above or below the motion segment
+    moved = (ho["hit"] == 1) & ((t < 0.0) | (t > 1.0)) & (ho["t"] < 100.0) & (np.abs(ho["pt"][:, 1] - 0.2) > 0.75) & (ho["pt"][:, 1] < 2.9)
+    assert moved.sum() > 100
