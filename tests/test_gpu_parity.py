@@ -444,3 +444,31 @@ def test_ray_times_outside_the_shutter_interval(pkg, gpu, oracle):
     # some of these hits are on spheres that have left their boxes: their centres lie above or below the motion segment
     moved = (ho["hit"] == 1) & ((t < 0.0) | (t > 1.0)) & (ho["t"] < 100.0) & (np.abs(ho["pt"][:, 1] - 0.2) > 0.75) & (ho["pt"][:, 1] < 2.9)
     assert moved.sum() > 100
+
+
+@pytest.mark.parametrize("cam", [
+    dict(image_width=1, aspect_ratio=16.0 / 9.0, samples_per_pixel=1, max_depth=5),      # (1 / 1.78) as u32 = 0 rows -> 1 (camera.rs:127-129)
+    dict(image_width=3, aspect_ratio=0.05, samples_per_pixel=4, max_depth=5),             # 3 x 60: a tall sliver
+    dict(image_width=40, aspect_ratio=2.0, samples_per_pixel=9, max_depth=50, defocus_angle=25.0, focus_distance=0.5, vertical_fov=150.0),
+    dict(image_width=33, aspect_ratio=1.3, samples_per_pixel=2, max_depth=1, vertical_fov=1.0),  # spp 2 -> 1 stratum; one segment per path
+])
+def test_camera_edge_cases(pkg, gpu, oracle, cam):
+    def build(be):
+        sc = be.new_scene()
+        pkg.scenes.random_spheres(sc, width=16, spp=1, depth=1)
+        sc.set_camera(look_from=(13.0, 2.0, 3.0), look_at=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), background=(0.7, 0.8, 1.0), **cam)
+        sc.commit()
+        return sc
+    sg, so = build(gpu), build(oracle)
+    assert sg.image_size() == so.image_size() and sg.sqrt_spp() == so.sqrt_spp()
+    w, h = sg.image_size()
+    q = sg.sqrt_spp()
+    xyss = np.array([(x, y, sx, sy) for y in range(h) for x in range(w) for sy in range(q) for sx in range(q)], dtype=np.uint32)
+    rg, ro = sg.camera_rays(xyss, seed=4), so.camera_rays(xyss, seed=4)
+    assert np.array_equal(rg.view(np.uint64), ro.view(np.uint64))
+    img_g, _, st_g = sg.render_frame(seed=4, flags=pkg.bindings.RENDER_EXACT_SHADING)
+    img_o, _, st_o = so.render_frame(seed=4, sum_dtype=np.float64)
+    assert img_g.shape == img_o.shape == (h, w, 3)
+    assert st_g["paths"] == st_o["paths"] == w * h * q * q and st_g["segments"] == st_o["segments"]
+    diff = np.abs(img_g.astype(np.float64) - img_o)
+    assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 5e-3
