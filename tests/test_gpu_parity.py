@@ -472,3 +472,21 @@ def test_camera_edge_cases(pkg, gpu, oracle, cam):
     assert st_g["paths"] == st_o["paths"] == w * h * q * q and st_g["segments"] == st_o["segments"]
     diff = np.abs(img_g.astype(np.float64) - img_o)
     assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 5e-3
+
+
+def test_degenerate_camera_all_nan_rays(pkg, gpu, oracle):
+    """`up` parallel to the view direction: camera.rs:146-148 normalises a zero vector and every ray is NaN.  NaN rays
+    fail every comparison of the intersection code, so the reference shows the background; so must the GPU path."""
+    out = []
+    for be in (gpu, oracle):
+        sc = be.new_scene()
+        pkg.scenes.random_spheres(sc, width=16, spp=1, depth=1)
+        sc.set_camera(image_width=24, aspect_ratio=1.5, samples_per_pixel=4, max_depth=6, look_from=(0.0, 5.0, 0.0), look_at=(0.0, 0.0, 0.0),
+                      up=(0.0, 1.0, 0.0), background=(0.7, 0.8, 1.0))
+        sc.commit()
+        img, rgb8, st = sc.render_frame(seed=1, want_rgb8=True, **({} if be is gpu else {"sum_dtype": np.float64}))
+        assert st["segments"] == st["paths"] == 24 * 16 * 4
+        out.append((img, rgb8))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-6)
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.all(out[0][1].reshape(-1, 3) == np.array([214, 228, 255]))
