@@ -490,3 +490,42 @@ def test_degenerate_camera_all_nan_rays(pkg, gpu, oracle):
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-6)
     assert np.array_equal(out[0][1], out[1][1])
     assert np.all(out[0][1].reshape(-1, 3) == np.array([214, 228, 255]))
+
+
+def test_negative_radius_sphere(pkg, gpu, oracle):
+    """The hollow-glass idiom: a sphere of negative radius inside a glass sphere.  Sphere::new keeps the sign
+    (sphere.rs:21-29), so the outward normal (p - c) / r points inward (sphere.rs:124)."""
+    def build(be):
+        sc = be.new_scene()
+        glass = sc.dielectric(1.5)
+        nodes = [
+            sc.sphere((0.0, -100.5, -1.0), 100.0, sc.lambertian_color(0.8, 0.8, 0.0)),
+            sc.sphere((0.0, 0.0, -1.0), 0.5, sc.lambertian_color(0.1, 0.2, 0.5)),
+            sc.sphere((-1.0, 0.0, -1.0), 0.5, glass),
+            sc.sphere((-1.0, 0.0, -1.0), -0.4, glass),
+            sc.sphere((1.0, 0.0, -1.0), -0.5, sc.metal(0.8, 0.6, 0.2, 0.3), direction=(0.0, 0.3, 0.0)),
+        ]
+        sc.set_world(sc.bvh(nodes))
+        sc.set_lights(None)
+        sc.set_camera(image_width=96, aspect_ratio=16.0 / 9.0, samples_per_pixel=16, max_depth=20, vertical_fov=40, look_from=(-2.0, 2.0, 1.0),
+                      look_at=(0.0, 0.0, -1.0), background=(0.7, 0.8, 1.0))
+        sc.commit()
+        return sc
+    sg, so = build(gpu), build(oracle)
+    for a, b in zip(sg.dump_tree(), so.dump_tree()):
+        assert np.array_equal(a, b)
+    rng = np.random.default_rng(4)
+    n = 50_000
+    o = np.array([-2.0, 2.0, 1.0]) + rng.normal(0.0, 0.3, (n, 3))
+    d = np.stack([rng.uniform(-2, 2, n), rng.uniform(-0.6, 0.8, n), rng.uniform(-2, 0, n)], axis=1) - o
+    t = rng.random(n)
+    hg, ho = sg.trace_rays(o, d, t, seed=1), so.trace_rays(o, d, t, seed=1)
+    info = compare_hits(hg, ho)
+    assert info["n_hit"] > n // 2
+    img_g, _, st_g = sg.render_frame(seed=3, flags=pkg.bindings.RENDER_EXACT_SHADING)
+    img_o, _, st_o = so.render_frame(seed=3, sum_dtype=np.float64)
+    assert st_g["segments"] == st_o["segments"]
+    diff = np.abs(img_g.astype(np.float64) - img_o)
+    assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
+    fast, _, _ = sg.render_frame(seed=3)
+    assert (np.abs(fast.astype(np.float64) - img_o) > 2e-3 * (1.0 + np.abs(img_o))).mean() < 1e-2
