@@ -529,3 +529,43 @@ def test_negative_radius_sphere(pkg, gpu, oracle):
     assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
     fast, _, _ = sg.render_frame(seed=3)
     assert (np.abs(fast.astype(np.float64) - img_o) > 2e-3 * (1.0 + np.abs(img_o))).mean() < 1e-2
+
+
+@pytest.mark.parametrize("root", ["group", "translated_bvh", "rotated_group_of_bvhs", "medium"])
+def test_world_root_shapes(pkg, gpu, oracle, root):
+    """SceneData.world is any Node (lib.rs:38-43), not necessarily a BoundingVolumeHierarchy: a plain Group (no
+    hierarchy in the scene at all), an instance around a hierarchy, a rotated Group of hierarchies, a ConstantMedium."""
+    def build(be):
+        sc = be.new_scene()
+        rng = np.random.default_rng(11)
+        mats = [sc.lambertian_color(0.7, 0.3, 0.3), sc.metal(0.8, 0.8, 0.8, 0.1), sc.dielectric(1.5)]
+        spheres = [sc.sphere(tuple(rng.uniform(-3, 3, 3)), float(rng.uniform(0.2, 0.6)), mats[i % 3]) for i in range(40)]
+        if root == "group":
+            world = sc.group(spheres)
+        elif root == "translated_bvh":
+            world = sc.translate(sc.bvh(spheres), (0.5, -0.25, 1.0))
+        elif root == "rotated_group_of_bvhs":
+            world = sc.rotate(sc.group([sc.bvh(spheres[:20]), sc.bvh(spheres[20:])]), (1.0, 1.0, 0.0), 33.0)
+        else:
+            world = sc.constant_medium_color(sc.sphere((0.0, 0.0, 0.0), 3.0, mats[2]), 0.4, 0.9, 0.9, 0.9)
+        sc.set_world(world)
+        sc.set_lights(None)
+        sc.set_camera(image_width=64, aspect_ratio=1.0, samples_per_pixel=16, max_depth=10, vertical_fov=50, look_from=(0.0, 1.0, 10.0),
+                      look_at=(0.0, 0.0, 0.0), background=(0.7, 0.8, 1.0))
+        sc.commit()
+        return sc
+    sg, so = build(gpu), build(oracle)
+    rng = np.random.default_rng(6)
+    n = 20000
+    o = np.array([0.0, 1.0, 10.0]) + rng.normal(0.0, 0.5, (n, 3))
+    d = rng.uniform(-4, 4, (n, 3)) - o
+    info = compare_hits(sg.trace_rays(o, d, None, seed=2), so.trace_rays(o, d, None, seed=2))
+    assert info["n_hit"] > n // 10
+    img_g, _, st_g = sg.render_frame(seed=3, flags=pkg.bindings.RENDER_EXACT_SHADING)
+    img_o, _, st_o = so.render_frame(seed=3, sum_dtype=np.float64)
+    assert st_g["segments"] == st_o["segments"]
+    diff = np.abs(img_g.astype(np.float64) - img_o)
+    assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
+    a, _, sa = sg.render_frame(seed=3)
+    b, _, sb = sg.render_frame(seed=3, flags=pkg.bindings.RENDER_REFERENCE_ORDER)
+    assert sa["segments"] == sb["segments"] and np.array_equal(a.view(np.uint32), b.view(np.uint32))
