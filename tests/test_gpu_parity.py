@@ -569,3 +569,46 @@ def test_world_root_shapes(pkg, gpu, oracle, root):
     a, _, sa = sg.render_frame(seed=3)
     b, _, sb = sg.render_frame(seed=3, flags=pkg.bindings.RENDER_REFERENCE_ORDER)
     assert sa["segments"] == sb["segments"] and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_shared_subgraphs_instanced_several_times(pkg, gpu, oracle):
+    """The scene graph is a DAG in the reference (Arc<dyn Node> clones): one hierarchy of spheres and one box placed
+    three times each through different instances, and one sphere that is a member of two hierarchies."""
+    def build(be):
+        sc = be.new_scene()
+        rng = np.random.default_rng(21)
+        mats = [sc.lambertian_color(0.2, 0.6, 0.3), sc.metal(0.9, 0.7, 0.4, 0.05), sc.dielectric(1.5), sc.lambertian_tex(sc.tex_checker(0.4, sc.tex_solid(0.1, 0.1, 0.1), sc.tex_solid(0.9, 0.9, 0.9)))]
+        cluster = sc.bvh([sc.sphere(tuple(rng.uniform(-0.8, 0.8, 3)), float(rng.uniform(0.1, 0.3)), mats[i % 4]) for i in range(24)])
+        box = sc.box((-0.4, -0.4, -0.4), (0.4, 0.4, 0.4), mats[3])
+        shared = sc.sphere((0.0, 0.0, 0.0), 0.5, mats[1])
+        world = [
+            sc.sphere((0.0, -1001.0, 0.0), 1000.0, mats[3]),
+            sc.translate(cluster, (-2.5, 0.0, 0.0)),
+            sc.translate(sc.rotate(cluster, (0.0, 0.0, 1.0), 90.0), (0.0, 0.0, 0.0)),
+            sc.translate(sc.scale(cluster, 1.5, 0.5, 1.0), (2.5, 0.0, 0.0)),
+            sc.translate(box, (-2.5, 1.6, 0.0)),
+            sc.translate(sc.rotate_y(box, 45.0), (0.0, 1.6, 0.0)),
+            sc.rotate(sc.translate(box, (2.5, 1.6, 0.0)), (1.0, 0.0, 0.0), 10.0),
+            sc.bvh([shared, sc.translate(shared, (0.0, 0.0, 2.0))]),
+            sc.translate(sc.bvh([shared]), (0.0, 0.0, -2.5)),
+        ]
+        sc.set_world(sc.bvh(world))
+        sc.set_lights(None)
+        sc.set_camera(image_width=96, aspect_ratio=1.5, samples_per_pixel=16, max_depth=12, vertical_fov=40, look_from=(0.0, 2.5, 9.0),
+                      look_at=(0.0, 0.5, 0.0), background=(0.7, 0.8, 1.0))
+        sc.commit()
+        return sc
+    sg, so = build(gpu), build(oracle)
+    for a, b in zip(sg.dump_tree(), so.dump_tree()):
+        assert np.array_equal(a, b)
+    rng = np.random.default_rng(6)
+    n = 40000
+    o = np.array([0.0, 2.5, 9.0]) + rng.normal(0.0, 0.3, (n, 3))
+    d = np.stack([rng.uniform(-4, 4, n), rng.uniform(-1, 2.5, n), rng.uniform(-3, 3, n)], axis=1) - o
+    info = compare_hits(sg.trace_rays(o, d, None, seed=2), so.trace_rays(o, d, None, seed=2))
+    assert info["n_hit"] > n // 2
+    img_g, _, st_g = sg.render_frame(seed=3, flags=pkg.bindings.RENDER_EXACT_SHADING)
+    img_o, _, st_o = so.render_frame(seed=3, sum_dtype=np.float64)
+    assert st_g["segments"] == st_o["segments"]
+    diff = np.abs(img_g.astype(np.float64) - img_o)
+    assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
