@@ -612,3 +612,31 @@ def test_shared_subgraphs_instanced_several_times(pkg, gpu, oracle):
     assert st_g["segments"] == st_o["segments"]
     diff = np.abs(img_g.astype(np.float64) - img_o)
     assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
+
+
+@pytest.mark.parametrize("spp", [10000, 65536 + 600])
+def test_many_strata_few_pixels(pkg, gpu, oracle, spp):
+    """100 x 100 and 257 x 257 strata on a handful of pixels (the Next-Week final configuration's 10 000 spp): the stratum
+    index arithmetic (sample -> (s_x, s_y), camera.rs:335-341) at sizes the other tests do not reach."""
+    def build(be):
+        sc = be.new_scene()
+        pkg.scenes.three_spheres(sc, width=16, spp=1, depth=1)
+        sc.set_camera(image_width=3, aspect_ratio=1.5, samples_per_pixel=spp, max_depth=6, vertical_fov=40, look_from=(-2.0, 2.0, 1.0),
+                      look_at=(0.0, 0.0, -1.0), background=(0.7, 0.8, 1.0), defocus_angle=4.0, focus_distance=3.4)
+        sc.commit()
+        return sc
+    sg, so = build(gpu), build(oracle)
+    q = sg.sqrt_spp()
+    assert q == so.sqrt_spp() == int(np.floor(np.sqrt(spp)))
+    w, h = sg.image_size()
+    rng = np.random.default_rng(1)
+    k = 20000
+    xyss = np.stack([rng.integers(0, w, k), rng.integers(0, h, k), rng.integers(0, q, k), rng.integers(0, q, k)], axis=1).astype(np.uint32)
+    xyss[:4] = [(0, 0, 0, 0), (w - 1, h - 1, q - 1, q - 1), (0, h - 1, q - 1, 0), (w - 1, 0, 0, q - 1)]
+    assert np.array_equal(sg.camera_rays(xyss, seed=9).view(np.uint64), so.camera_rays(xyss, seed=9).view(np.uint64))
+    img_g, _, st_g = sg.render_frame(seed=9, flags=pkg.bindings.RENDER_EXACT_SHADING)
+    img_o, _, st_o = so.render_frame(seed=9, sum_dtype=np.float64)
+    assert st_g["paths"] == st_o["paths"] == w * h * q * q and st_g["segments"] == st_o["segments"]
+    # a pixel is the sum of tens of thousands of samples here; the few paths per pixel that part ways with the oracle's
+    # (last-bit differences between the device's and glibc's libm, amplified by the bounces) move it by parts in 10^4
+    np.testing.assert_allclose(img_g, img_o, rtol=2e-3)
