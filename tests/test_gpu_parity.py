@@ -640,3 +640,45 @@ def test_many_strata_few_pixels(pkg, gpu, oracle, spp):
     # a pixel is the sum of tens of thousands of samples here; the few paths per pixel that part ways with the oracle's
     # (last-bit differences between the device's and glibc's libm, amplified by the bounces) move it by parts in 10^4
     np.testing.assert_allclose(img_g, img_o, rtol=2e-3)
+
+
+def test_textures_on_every_primitive_under_instances(pkg, gpu, oracle):
+    """Noise, turbulence, nested checker and image textures (texture/*.rs) read (u, v, p) of hit records that come back
+    through Translate / Rotate / Scale: on a quad, a box, a disc, a cone frustum and an ellipsoid; also as the emission
+    of a light and as the albedo of a medium."""
+    S = pkg.scenes
+
+    def build(be):
+        sc = be.new_scene()
+        rng = S.SceneRandom(5)
+        noise = sc.tex_perlin_noise(3.0, S.perlin_tables(rng))
+        turb = sc.tex_perlin_turbulence(1.5, 5, S.perlin_tables(rng))
+        img = sc.tex_image(S.earth_texels()[::8, ::8].copy())
+        inner = sc.tex_checker(0.25, noise, sc.tex_solid(0.9, 0.2, 0.2))
+        nested = sc.tex_checker(1.0, inner, img)
+        m_noise, m_turb, m_img, m_nested = (sc.lambertian_tex(t) for t in (noise, turb, img, nested))
+        glow = sc.diffuse_light_tex(turb)
+        world = [
+            sc.quad((-6.0, -1.0, -6.0), (12.0, 0.0, 0.0), (0.0, 0.0, 12.0), m_nested),
+            sc.translate(sc.rotate_y(sc.box((-0.6, -0.6, -0.6), (0.6, 0.6, 0.6), m_img), 30.0), (-2.5, 0.0, 0.0)),
+            sc.translate(sc.scale(sc.sphere((0.0, 0.0, 0.0), 1.0, m_turb), 1.4, 0.7, 1.0), (0.0, 0.0, 0.0)),
+            sc.rotate(sc.translate(sc.disc((0.0, 0.0, 0.0), 1.0, (0.0, 1.0, 0.0), m_noise), (2.5, 0.2, 0.0)), (0.0, 0.0, 1.0), 12.0),
+            sc.translate(sc.cone_frustum((0.0, -1.0, 0.0), 1.5, 0.2, 0.7, m_img), (0.0, 0.0, -2.5)),
+            sc.quad((-1.0, 3.0, -1.0), (2.0, 0.0, 0.0), (0.0, 0.0, 2.0), glow),
+            sc.constant_medium_tex(sc.sphere((2.5, 1.5, -2.0), 0.9, m_img), 1.5, nested),
+            sc.sphere((-2.5, 1.5, -2.0), 0.8, m_nested, direction=(0.0, 0.4, 0.0)),
+        ]
+        sc.set_world(sc.bvh(world))
+        sc.set_lights(sc.group([world[5]]))
+        sc.set_camera(image_width=96, aspect_ratio=1.5, samples_per_pixel=16, max_depth=10, vertical_fov=45, look_from=(0.0, 3.0, 9.0),
+                      look_at=(0.0, 0.3, 0.0), background=(0.3, 0.35, 0.45))
+        sc.commit()
+        return sc
+    sg, so = build(gpu), build(oracle)
+    img_g, _, st_g = sg.render_frame(seed=3, flags=pkg.bindings.RENDER_EXACT_SHADING)
+    img_o, _, st_o = so.render_frame(seed=3, sum_dtype=np.float64)
+    assert st_g["segments"] == st_o["segments"]
+    diff = np.abs(img_g.astype(np.float64) - img_o)
+    assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 3e-3
+    fast, _, _ = sg.render_frame(seed=3)
+    assert (np.abs(fast.astype(np.float64) - img_o) > 2e-3 * (1.0 + np.abs(img_o))).mean() < 1.5e-2
