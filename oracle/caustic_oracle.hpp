@@ -498,6 +498,15 @@ struct Node {  // object/mod.rs:54-68
   virtual Vec3 random(RenderContext&, const Vec3&) const { return Vec3(1.0, 0.0, 0.0); }
   // Adds v to the number of times one world.hit reaches every ConstantMedium below this node.
   virtual void count_tests(int) {}
+  // A scene graph is a DAG (the reference shares Arc<dyn Node>s), and the reference draws a fresh free-flight
+  // sample every time a ray reaches a ConstantMedium, whichever way it came.  To address those samples by key
+  // (see ConstantMedium) every place a medium occupies in the world needs an identity of its own, so the world is
+  // expanded into a tree wherever it holds media: instantiate() returns the node itself for a subtree without
+  // media and a copy with instantiated children otherwise; number_media() then hands every medium of the
+  // expanded tree, in depth-first order, the keys of its samples.
+  virtual bool holds_medium() const { return false; }
+  virtual std::shared_ptr<Node> instantiate(const std::shared_ptr<Node>& self) const { return self; }
+  virtual void number_media(uint32_t&) {}
 };
 using NodeP = std::shared_ptr<Node>;
 
@@ -800,6 +809,18 @@ struct Group : Node {
   }
   int kind() const override { return K_GROUP; }
   void count_tests(int v) override { for (const NodeP& n : nodes) n->count_tests(v); }
+  bool holds_medium() const override {
+    for (const NodeP& n : nodes)
+      if (n->holds_medium()) return true;
+    return false;
+  }
+  NodeP instantiate(const NodeP& self) const override {
+    if (!holds_medium()) return self;
+    auto c = std::make_shared<Group>(*this);
+    for (NodeP& n : c->nodes) n = n->instantiate(n);
+    return c;
+  }
+  void number_media(uint32_t& next) override { for (const NodeP& n : nodes) n->number_media(next); }
   // group.rs:44-54
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     bool any = false;
@@ -1035,6 +1056,14 @@ struct Translate : Node {
   Translate(NodeP o, const Vec3& off) : object(std::move(o)), offset(off) { bbox = object->bounding_box().translated(off); }
   int kind() const override { return K_TRANSLATE; }
   void count_tests(int v) override { object->count_tests(v); }
+  bool holds_medium() const override { return object->holds_medium(); }
+  NodeP instantiate(const NodeP& self) const override {
+    if (!holds_medium()) return self;
+    auto c = std::make_shared<Translate>(*this);
+    c->object = object->instantiate(object);
+    return c;
+  }
+  void number_media(uint32_t& next) override { object->number_media(next); }
   // translate.rs:26-37
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     Ray offset_r(ray.origin - offset, ray.direction, ray.time);
@@ -1091,6 +1120,14 @@ struct Rotate : Node {
   }
   int kind() const override { return K_ROTATE; }
   void count_tests(int v) override { object->count_tests(v); }
+  bool holds_medium() const override { return object->holds_medium(); }
+  NodeP instantiate(const NodeP& self) const override {
+    if (!holds_medium()) return self;
+    auto c = std::make_shared<Rotate>(*this);
+    c->object = object->instantiate(object);
+    return c;
+  }
+  void number_media(uint32_t& next) override { object->number_media(next); }
   // rotate.rs:135-149
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     Ray rotated_r(inv.mul(ray.origin), inv.mul(ray.direction), ray.time);
@@ -1124,6 +1161,14 @@ struct Scale : Node {
   }
   int kind() const override { return K_SCALE; }
   void count_tests(int v) override { object->count_tests(v); }
+  bool holds_medium() const override { return object->holds_medium(); }
+  NodeP instantiate(const NodeP& self) const override {
+    if (!holds_medium()) return self;
+    auto c = std::make_shared<Scale>(*this);
+    c->object = object->instantiate(object);
+    return c;
+  }
+  void number_media(uint32_t& next) override { object->number_media(next); }
   // scale.rs:95-117: t is kept; the normal goes through the inverse matrix and is re-normalised
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     Ray scaled_r(inv.mul(ray.origin), inv.mul(ray.direction), ray.time);
@@ -1149,9 +1194,22 @@ struct ConstantMedium : Node {
   // a medium more than once when a BoundingVolumeHierarchy holds it as both children (bvh.rs:22-26).  `tests`
   // is that count (set by count_tests from the world root); hit() takes the nearest of `tests` keyed samples
   // every time it is called, which has the same distribution as the reference's sequence of tests and makes
-  // the outcome independent of the visiting order.
+  // the outcome independent of the visiting order.  The samples are addressed by sample_base .. sample_base +
+  // tests - 1, numbers no other medium of the (expanded, see Node::instantiate) world shares, so media met along
+  // one ray draw independently, as they do from the reference's stream.
   int tests = 0;
+  uint32_t sample_base = 0;
   void count_tests(int v) override { tests += v; }
+  bool holds_medium() const override { return true; }
+  NodeP instantiate(const NodeP&) const override {
+    auto c = std::make_shared<ConstantMedium>(*this);
+    c->tests = 0;
+    return c;
+  }
+  void number_media(uint32_t& next) override {
+    sample_base = next;
+    next += (uint32_t)tests;
+  }
   // constant_medium.rs:41-80
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     HitRecord hit1, hit2;
@@ -1163,8 +1221,8 @@ struct ConstantMedium : Node {
     if (hit1.t < 0.0) hit1.t = 0.0;
     double ray_length = ray.direction.length();
     double distance_inside_boundary = (hit2.t - hit1.t) * ray_length;
-    double u = ctx.random->rand_keyed((uint32_t)id);
-    for (int j = 1; j < tests; j++) u = std::fmax(u, ctx.random->rand_keyed((uint32_t)id | ((uint32_t)j << 24)));
+    double u = ctx.random->rand_keyed(sample_base);
+    for (int j = 1; j < tests; j++) u = std::fmax(u, ctx.random->rand_keyed(sample_base + (uint32_t)j));
     double hit_distance = neg_inv_density * std::log(u);
     if (hit_distance > distance_inside_boundary) return false;
     double t = hit1.t + hit_distance / ray_length;
@@ -1222,6 +1280,18 @@ struct BVH : Node {
   }
   int kind() const override { return K_BVH; }
   void count_tests(int v) override { left->count_tests(v); right->count_tests(v); }  // a single object is both children
+  bool holds_medium() const override { return left->holds_medium() || right->holds_medium(); }
+  NodeP instantiate(const NodeP& self) const override {
+    if (!holds_medium()) return self;
+    auto c = std::make_shared<BVH>(*this);
+    c->left = left->instantiate(left);
+    c->right = right == left ? c->left : right->instantiate(right);  // one object held twice stays one object
+    return c;
+  }
+  void number_media(uint32_t& next) override {
+    left->number_media(next);
+    if (right != left) right->number_media(next);
+  }
   // bvh.rs:58-76
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
     ctx.n_bvh_visits++;

@@ -128,7 +128,10 @@ struct alignas(8) DMedium {
   nref_t xform;
   int32_t leaf_id;
   uint32_t tests;  // times one world.hit of the reference tests this medium, each with a fresh free-flight sample
-  uint32_t pad;
+  // Those samples are the keyed uniforms sample_base .. sample_base + tests - 1 of the path's bounce: every record
+  // (a medium node instanced in several places of the scene graph gives one record per place) owns its own keys, so
+  // the media a ray meets draw independently, as they do from the reference's stream (constant_medium.rs:64).
+  uint32_t sample_base;
 };
 
 enum : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_DIFFUSE_LIGHT = 3, MK_ISOTROPIC = 4, MK_EMPTY = 5, MK_COUNT = 6 };

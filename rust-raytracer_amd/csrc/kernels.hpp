@@ -900,8 +900,8 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
             // medium more than once per world.hit when the medium is the only object of a BoundingVolumeHierarchy
             // (m.tests).  The nearest of those exponential samples comes from the largest uniform; taking all of
             // them on every visit makes the visit idempotent and independent of the visiting order.
-            double u = rng.keyed((uint32_t)m.leaf_id);
-            for (uint32_t j = 1; j < m.tests; j++) u = fmax(u, rng.keyed((uint32_t)m.leaf_id | (j << 24)));
+            double u = rng.keyed(m.sample_base);
+            for (uint32_t j = 1; j < m.tests; j++) u = fmax(u, rng.keyed(m.sample_base + j));
             double hit_distance = m.neg_inv_density * log(u);
             if (!(hit_distance > inside)) {
               best_t = t1 + hit_distance / ray_length;

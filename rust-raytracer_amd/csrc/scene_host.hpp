@@ -413,6 +413,7 @@ struct HostScene {
     const HostScene& H;
     Flat& F;
     uint32_t seq = 0;  // primitives emitted so far, in the reference's depth-first visiting order
+    uint64_t medium_samples = 0;  // free-flight sample keys handed out so far (DMedium::sample_base)
     explicit Flattener(const HostScene& h, Flat& f) : H(h), F(f) {}
 
     void chain_of(nref_t x, std::vector<nref_t>& out) const {
@@ -607,6 +608,10 @@ struct HostScene {
           if (in_boundary) throw std::runtime_error("a ConstantMedium inside another medium's boundary is not supported");
           size_t idx = F.media.size();
           F.media.push_back(DMedium{});
+          // keys in depth-first order of the expanded graph: a medium node reached along two ways is two media
+          const uint32_t sample_base = (uint32_t)medium_samples;
+          medium_samples += tests;
+          if (medium_samples >= (1ull << 31)) throw std::runtime_error("too many ConstantMedium samples per ray segment (2^31 at most)");
           nref_t b = emit(n.c0, xform, true, -1);
           DMedium& m = F.media[idx];
           m.neg_inv_density = n.a[0];
@@ -615,6 +620,7 @@ struct HostScene {
           m.xform = xform;
           m.leaf_id = n.id;
           m.tests = tests;
+          m.sample_base = sample_base;
           return NREF(NK_MEDIUM, idx);
         }
       }

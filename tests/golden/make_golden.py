@@ -1,4 +1,4 @@
-"""Generates tests/golden/golden_v1.npz from the CPU oracle: for each named scene a fixed ray set with the
+"""Generates tests/golden/golden_v2.npz from the CPU oracle: for each named scene a fixed ray set with the
 oracle's hit records, and a tiny radiance-sum image.  The reference holds no vectors for this level
 (no ray/hit fixture, no image test), so these pin the oracle against regressions and give the GPU
 tests committed numbers to hit; they are produced by this repo's restatement, not by the reference.
@@ -50,6 +50,6 @@ for name in SCENES:
     out[name + "/tree_ids"] = ids
     out[name + "/tree_boxes"] = boxes
     print(name, len(t), "rays", int(hits["hit"].sum()), "hits", "segments", st["segments"])
-path = os.path.join(ROOT, "tests", "golden", "golden_v1.npz")
+path = os.path.join(ROOT, "tests", "golden", "golden_v2.npz")
 np.savez_compressed(path, **out)
 print(path, os.path.getsize(path))

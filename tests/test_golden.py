@@ -1,4 +1,4 @@
-"""Committed golden vectors (tests/golden/golden_v1.npz, produced by tests/golden/make_golden.py from
+"""Committed golden vectors (tests/golden/golden_v2.npz, produced by tests/golden/make_golden.py from
 the oracle): the oracle must keep reproducing them on the CPU, and the GPU path must hit the same
 numbers through the C ABI."""
 import os
@@ -13,7 +13,7 @@ KW = dict(width=32, spp=4, depth=8)
 
 @pytest.fixture(scope="module")
 def golden():
-    return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_v2.npz"))
 
 
 def _check(sc, g, name, exact_image, sum_dtype, flags=0):

@@ -76,3 +76,57 @@ def test_gpu_single_member_and_empty_hierarchies(oracle, gpu):
     assert np.array_equal(got["leaf_id"], want["leaf_id"])
     m = want["hit"] == 1
     assert np.array_equal(got["t"][m], want["t"][m])
+
+
+def _shared_scene(be, density=0.5, how="translates"):
+    """One ConstantMedium node placed twice in the world (the reference shares Arc<dyn Node>s the same way).  Each
+    copy draws its own free-flight sample whenever a ray reaches it (constant_medium.rs:64), so a ray through both
+    sees exp(-density * (A + B))."""
+    sc = be.new_scene()
+    lam = sc.lambertian_color(0.5, 0.5, 0.5)
+    medium = sc.constant_medium_color(sc.sphere((0.0, 0.0, 0.0), 1.0, lam), density, 1.0, 1.0, 1.0)
+    far = sc.sphere((0.0, 50.0, 0.0), 1.0, lam)
+    if how == "translates":
+        # four members: the hierarchy splits them two and two, so neither copy sits alone in a sub-hierarchy (which
+        # would test it twice, bvh.rs:27-28)
+        members = [sc.translate(medium, (0.0, 0.0, -2.0)), sc.translate(medium, (0.0, 0.0, 2.0)), far, sc.sphere((0.0, 60.0, 0.0), 1.0, lam)]
+        world = sc.bvh(members)
+    elif how == "group_twice":  # the same node twice in one Group: tested twice per world.hit, like two media in one place
+        world = sc.group([medium, medium, far])
+    else:  # nested single-member hierarchies: 2 x 2 tests of the one medium
+        world = sc.bvh([sc.bvh([sc.bvh([medium])]), far])
+    sc.set_world(world)
+    sc.set_camera(image_width=24, samples_per_pixel=16, max_depth=6, vertical_fov=30, look_from=(0.5, 0.3, 14), look_at=(0, 0, 0), background=(1, 1, 1))
+    sc.commit()
+    return sc
+
+
+@pytest.mark.parametrize("how,inside", [("translates", 4.0), ("group_twice", 4.0), ("nested_single", 8.0)])
+def test_oracle_shared_medium_draws_independently(oracle, how, inside):
+    n = 60_000
+    o, d = _rays(n)
+    o[:, 2] = -8.0
+    hits = _shared_scene(oracle, how=how).trace_rays(o, d, seed=3)
+    expected = np.exp(-0.5 * inside)
+    transmitted = 1.0 - hits["hit"].mean()
+    assert abs(transmitted - expected) < 4.0 * np.sqrt(expected * (1.0 - expected) / n) + 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how,inside", [("translates", 4.0), ("group_twice", 4.0), ("nested_single", 8.0)])
+def test_gpu_shared_medium_equals_oracle(pkg, oracle, gpu, how, inside):
+    n = 60_000
+    o, d = _rays(n)
+    o[:, 2] = -8.0
+    sg, so = _shared_scene(gpu, how=how), _shared_scene(oracle, how=how)
+    want, got = so.trace_rays(o, d, seed=3), sg.trace_rays(o, d, seed=3)
+    assert np.array_equal(got["hit"], want["hit"])
+    m = want["hit"] == 1
+    assert np.array_equal(got["leaf_id"][m], want["leaf_id"][m])
+    assert np.abs(got["t"][m] - want["t"][m]).max() <= 1e-12 * np.abs(want["t"][m]).max()
+    expected = np.exp(-0.5 * inside)
+    assert abs((1.0 - got["hit"].mean()) - expected) < 4.0 * np.sqrt(expected * (1.0 - expected) / n) + 1e-3
+    e, _, se = sg.render_frame(seed=2, flags=pkg.bindings.RENDER_EXACT_SHADING)
+    o_img, _, so_st = so.render_frame(seed=2, sum_dtype=np.float64)
+    assert se["segments"] == so_st["segments"]
+    assert (np.abs(e.astype(np.float64) - o_img) > 1e-3 * (1.0 + np.abs(o_img))).mean() < 2e-3
