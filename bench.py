@@ -43,7 +43,7 @@ def cpu_baseline(width, depth, seed):
         import subprocess
 
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
-    orc = pkg.bindings.Backend(C.CDLL(oracle_so), "orc_", "oracle")
+    orc = pkg.bindings.Backend(C.CDLL(oracle_so), "orc_", "oracle", sum_dtype="float64")
     threads = min(os.cpu_count() or 1, 16)
     spp = 64
     so = pkg.scenes.build(orc, "random_spheres", width=width, spp=spp, depth=depth)

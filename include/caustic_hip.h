@@ -214,6 +214,18 @@ int chip_resolve_device(chip_scene* s, const float* d_sum_rgb, size_t npixels, f
 int chip_resolve_device_flags(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, uint32_t flags,
                               void* stream);
 
+/* One frame over several GPUs of the machine, from one process: the shape of the reference's caller, which deals the
+ * work of a frame to `num_cpus` threads and gathers their results (crates/cli/src/main.rs:119-186).
+ * chip_commit_devices copies the committed scene to every device in `devices` (n entries, 1..64; an id may occur more
+ * than once, each entry gets a replica of its own, which is how a one-GPU machine runs this path).  It must be called
+ * again after every chip_commit.  chip_render_frame_multi then renders like chip_render_frame: replica g takes every
+ * n-th of the strata the call covers (stratum_offset + g * stride, stride * n) on a host thread of its own, the f32
+ * radiance sums are copied to the first device over the GPU interconnect (peer copies) and added there in replica
+ * order, so the image does not depend on timing, and the first device resolves it.  The sums equal the one-GPU
+ * frame's up to the order of f32 additions.  stats: counts are summed over the replicas, ms_total is the slowest. */
+int chip_commit_devices(chip_scene* s, const int* devices, int n);
+int chip_render_frame_multi(chip_scene* s, const chip_render_opts* opts, float* out_sum_rgb, uint8_t* out_rgb8, chip_stats* stats);
+
 /* Test hooks.  chip_trace_rays: closest hit of world over [0.001, inf) (camera.rs:264) for n host
  * rays (origin, direction: n x 3 doubles; time: n doubles or NULL = 0; any time is accepted, also outside
  * the [0, 1) the camera draws, ray.rs / camera.rs:371).  Medium free-flight draws use the Philox stream keyed

@@ -126,10 +126,11 @@ def _ptr(a, ctype):
 class Backend:
     """One loaded library exporting `<prefix>scene_create`, `<prefix>sphere`, ..."""
 
-    def __init__(self, lib: C.CDLL, prefix: str, name: str):
+    def __init__(self, lib: C.CDLL, prefix: str, name: str, sum_dtype=np.float32):
         self.lib = lib
         self.prefix = prefix
         self.name = name
+        self.sum_dtype = np.dtype(sum_dtype)  # what render_frame writes: the GPU library float, the oracle double
         self._declare()
 
     def fn(self, name):
@@ -192,6 +193,8 @@ class Backend:
             "render_accumulate_device": (i, [p, C.POINTER(RenderOpts), p, p, C.POINTER(Stats)]),
             "resolve_device": (i, [p, p, C.c_size_t, p, p, p]),
             "scene_from_flat": (C.c_int64, [p, C.POINTER(FlatScene), pi32]),
+            "commit_devices": (i, [p, pi32, i]),
+            "render_frame_multi": (i, [p, C.POINTER(RenderOpts), p, C.POINTER(C.c_uint8), C.POINTER(Stats)]),
         }.items():
             if hasattr(self.lib, self.prefix + name):
                 f = self.fn(name)
@@ -451,15 +454,20 @@ class Scene:
             return h, w
         return rect[3] - rect[2], rect[1] - rect[0]
 
-    def render_frame(self, seed=1, stratum_offset=0, stratum_stride=1, rect=None, strata_per_batch=0, flags=0, want_rgb8=False, sum_dtype=np.float32):
-        """Returns (sum_rgb[h,w,3], rgb8 or None, stats dict).  sum_rgb is the un-normalised radiance sum."""
+    def render_frame(self, seed=1, stratum_offset=0, stratum_stride=1, rect=None, strata_per_batch=0, flags=0, want_rgb8=False, sum_dtype=None,
+                     multi=False):
+        """Returns (sum_rgb[h,w,3], rgb8 or None, stats dict).  sum_rgb is the un-normalised radiance sum, in the
+        backend's own type (passing another `sum_dtype` is an error: the library writes its type into the buffer).
+        `multi` renders through `render_frame_multi` (after `commit_devices`)."""
+        if sum_dtype is not None and np.dtype(sum_dtype) != self.be.sum_dtype:
+            raise CausticError(f"{self.be.name} writes {self.be.sum_dtype} radiance sums, not {np.dtype(sum_dtype)}")
         o = self._opts(seed, stratum_offset, stratum_stride, rect, strata_per_batch, flags)
         rh, rw = self._rect_shape(rect)
-        out = np.zeros((rh, rw, 3), dtype=sum_dtype)
+        out = np.zeros((rh, rw, 3), dtype=self.be.sum_dtype)
         rgb8 = np.zeros((rh, rw, 3), dtype=np.uint8) if want_rgb8 else None
         st = Stats()
         self._call(
-            "render_frame",
+            "render_frame_multi" if multi else "render_frame",
             C.byref(o),
             out.ctypes.data_as(C.c_void_p),
             _ptr(rgb8, C.c_uint8) if want_rgb8 else None,
@@ -473,6 +481,10 @@ class Scene:
         st = Stats()
         self._call("render_accumulate_device", C.byref(o), C.c_void_p(d_sum_ptr), C.c_void_p(stream), C.byref(st))
         return st.as_dict()
+
+    def commit_devices(self, devices):
+        a = np.ascontiguousarray(devices, dtype=np.int32)
+        return self._call("commit_devices", _ptr(a, C.c_int32), int(a.size))
 
     def resolve_device(self, d_sum_ptr: int, npixels: int, d_gamma_ptr: int = 0, d_rgb8_ptr: int = 0, stream=0):
         return self._call(

@@ -4,8 +4,11 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <functional>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -42,6 +45,8 @@ struct DevBuf {
     n = count;
     return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
   }
+  // keeps the buffer when it is already large enough
+  hipError_t reserve(size_t count) { return (p && n >= count) ? hipSuccess : alloc(count); }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -49,12 +54,86 @@ struct DevBuf {
   }
 };
 
-struct chip_scene {
-  HostScene host;
-  bool committed = false;
-  int device = 0;
+// The calling thread's current device is put back when a library call returns.
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+// Events made during one render call; destroyed on every way out of it (after the device has gone idle when the
+// call fails midway, so that no queued work still refers to them).
+struct EventBag {
+  std::vector<hipEvent_t> evs;
+  bool failed = false;
+  hipError_t make(hipEvent_t* out, bool timing) {
+    hipError_t e = timing ? hipEventCreate(out) : hipEventCreateWithFlags(out, hipEventDisableTiming);
+    if (e == hipSuccess) evs.push_back(*out);
+    else *out = nullptr;
+    return e;
+  }
+  ~EventBag() {
+    if (failed) (void)hipDeviceSynchronize();
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+  }
+};
+
+// ---- scratch of the entry point that allocates nothing (chip_render_accumulate_noalloc)
+// One path pool of CHIP_NOALLOC_PATHS slots with its counters, spill slab, error flags and statistics, laid out
+// in a file-scope device array.  Every GPU the library runs on holds its own copy of the array at its own
+// address; host code never uses the array's name as a pointer, only the address hipGetSymbolAddress returned
+// for the device at hand (DeviceState::noalloc_base).
+#define CHIP_NOALLOC_PATHS 32768u
+#define CHIP_NOALLOC_COUNTER_ROWS 256u
+struct NoAllocLayout {
+  PathRay ray[2 * CHIP_NOALLOC_PATHS];
+  PathMap st[2 * CHIP_NOALLOC_PATHS];
+  PathHit hit[CHIP_NOALLOC_PATHS];
+  float4 sample[CHIP_NOALLOC_PATHS];
+  uint32_t qlit[CHIP_NOALLOC_PATHS];
+  uint32_t counters[CHIP_NOALLOC_COUNTER_ROWS * CHIP_CTR_STRIDE];
+  uint32_t ovf[(size_t)CHIP_NOALLOC_PATHS * 2 * CHIP_STACK_OVF];  // one spill slab per thread; a launch has at most one thread per slot
+  uint32_t err[4];
+  unsigned long long stats[4];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocLayout)];
+
+// Path pools.  A render of several batches runs two batches at a time, each in its own pool on its own
+// stream, so that one batch's traversal (VALU-bound) overlaps the other's shading (HBM-bound).
+struct PoolBufs {
+  bool ready = false;
+  PathPool P{};
+  DevBuf<PathRay> ray;
+  DevBuf<PathHit> hit;
+  DevBuf<PathMap> st;
+  DevBuf<float4> sample;
+  DevBuf<uint32_t> qlit, counters, ovf;
+  uint32_t counters_rows = 0;
+  void release() {
+    ray.release(); hit.release(); st.release(); sample.release();
+    qlit.release(); counters.release(); ovf.release();
+    ready = false;
+    counters_rows = 0;
+    P = PathPool{};
+  }
+};
+// What a batch in flight needs besides its pool: made once per device at commit, so a render call creates none of it.
+struct LaneRes {
+  uint32_t* h_live = nullptr;  // pinned: live-count readbacks (ring of four)
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_rb[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_join = nullptr;
+};
+static constexpr int kMaxLanes = 4;
+
+// Everything a scene keeps on one GPU: its tables, path pools, streams, events, pinned words and frame buffers.
+struct DeviceState {
+  int device = -1;
   int n_cus = 256;
-  Flat flat;
+  bool uploaded = false;
   DevBuf<DBvhNode> d_bvh;
   DevBuf<DTNode> d_tnodes;
   DevBuf<DSphere> d_spheres;
@@ -75,46 +154,65 @@ struct chip_scene {
   DevBuf<uint8_t> d_texels;
   DevBuf<DLight> d_lights;
   DScene dscene;
-  // Path pools.  A render of several batches runs two batches at a time, each in its own pool on its own
-  // stream, so that one batch's traversal (VALU-bound) overlaps the other's shading (HBM-bound).
-  struct PoolBufs {
-    bool ready = false;
-    PathPool P{};
-    DevBuf<PathRay> ray;
-    DevBuf<PathHit> hit;
-    DevBuf<PathMap> st;
-    DevBuf<float4> sample;
-    DevBuf<uint32_t> qlit, counters, ovf;
-    uint32_t counters_rows = 0;
-    uint32_t* h_live = nullptr;  // pinned: live-count readback
-    hipStream_t stream = nullptr;
-    void release() {
-      ray.release(); hit.release(); st.release(); sample.release();
-      qlit.release(); counters.release(); ovf.release();
-      if (h_live) (void)hipHostFree(h_live);
-      h_live = nullptr;
-      if (stream) (void)hipStreamDestroy(stream);
-      stream = nullptr;
-      ready = false;
-      counters_rows = 0;
-      P = PathPool{};
-    }
-  };
-  static constexpr int kMaxLanes = 4;
   PoolBufs pools[kMaxLanes];
+  LaneRes lanes[kMaxLanes];
+  bool res_ready = false;
   DevBuf<uint32_t> p_err;
   DevBuf<unsigned long long> p_stats;
   uint32_t* h_pinned = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr;
+  DevBuf<float> frame_sum, frame_stage;  // chip_render_frame's radiance sums; a peer's sums on their way into them
+  DevBuf<uint8_t> frame_rgb8;
+  unsigned char* noalloc_base = nullptr;  // this device's copy of `scratch`
+  PathPool noalloc_pool{};
 
-  void release_device() {
+  void release_tables() {
     d_bvh.release(); d_tnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release(); d_gbox.release();
     d_translates.release(); d_rotates.release(); d_scales.release(); d_discs.release(); d_cones.release(); d_media.release(); d_xchain.release(); d_materials.release();
     d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
-    for (int k = 0; k < kMaxLanes; k++) pools[k].release();
+    uploaded = false;
+  }
+  // (with this state's device current)
+  void release_all() {
+    release_tables();
+    for (int k = 0; k < kMaxLanes; k++) {
+      pools[k].release();
+      LaneRes& L = lanes[k];
+      if (L.h_live) (void)hipHostFree(L.h_live);
+      if (L.stream) (void)hipStreamDestroy(L.stream);
+      for (int j = 0; j < 4; j++)
+        if (L.ev_rb[j]) (void)hipEventDestroy(L.ev_rb[j]);
+      if (L.ev_join) (void)hipEventDestroy(L.ev_join);
+      L = LaneRes{};
+    }
     p_err.release();
     p_stats.release();
     if (h_pinned) (void)hipHostFree(h_pinned);
     h_pinned = nullptr;
+    for (hipEvent_t* e : {&ev0, &ev1, &ev_fork}) {
+      if (*e) (void)hipEventDestroy(*e);
+      *e = nullptr;
+    }
+    frame_sum.release(); frame_stage.release(); frame_rgb8.release();
+    res_ready = false;
+    noalloc_base = nullptr;
+    noalloc_pool = PathPool{};
+  }
+};
+
+struct chip_scene {
+  HostScene host;
+  bool committed = false;
+  Flat flat;
+  DeviceState dev;                                      // the device chip_commit ran on
+  std::vector<std::unique_ptr<DeviceState>> replicas;   // chip_commit_devices: one per entry of its device list
+
+  void release_device() {
+    DeviceGuard guard;
+    if (dev.device >= 0 && hipSetDevice(dev.device) == hipSuccess) dev.release_all();
+    for (auto& r : replicas)
+      if (r && r->device >= 0 && hipSetDevice(r->device) == hipSuccess) r->release_all();
+    replicas.clear();
     committed = false;
   }
 };
@@ -152,9 +250,44 @@ static size_t pool_capacity_max() {
 }
 static const size_t kBytesPerPathSlot = 2 * sizeof(PathRay) + sizeof(PathHit) + 2 * sizeof(PathMap) + sizeof(float4) + sizeof(uint32_t);
 
+// The small per-device resources of a scene (with the device current): streams, events, pinned words, error and
+// statistics words, and the address of this device's copy of the no-allocation scratch.
+static int ensure_resources(DeviceState& D) {
+  if (D.res_ready) return 0;
+  HIP_TRY(D.p_err.reserve(4));
+  HIP_TRY(D.p_stats.reserve(4));
+  if (!D.h_pinned) HIP_TRY(hipHostMalloc((void**)&D.h_pinned, 64 * sizeof(uint32_t), hipHostMallocDefault));
+  for (int k = 0; k < kMaxLanes; k++) {
+    LaneRes& L = D.lanes[k];
+    if (!L.h_live) HIP_TRY(hipHostMalloc((void**)&L.h_live, 16 * sizeof(uint32_t), hipHostMallocDefault));
+    if (!L.stream) HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    for (int j = 0; j < 4; j++)
+      if (!L.ev_rb[j]) HIP_TRY(hipEventCreateWithFlags(&L.ev_rb[j], hipEventDisableTiming));
+    if (!L.ev_join) HIP_TRY(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
+  }
+  if (!D.ev0) HIP_TRY(hipEventCreate(&D.ev0));
+  if (!D.ev1) HIP_TRY(hipEventCreate(&D.ev1));
+  if (!D.ev_fork) HIP_TRY(hipEventCreateWithFlags(&D.ev_fork, hipEventDisableTiming));
+  {
+    void* base = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&base, HIP_SYMBOL(scratch)));
+    if (!base) return fail("hipGetSymbolAddress returned no address for the no-allocation scratch");
+    D.noalloc_base = static_cast<unsigned char*>(base);
+    NoAllocLayout* L = reinterpret_cast<NoAllocLayout*>(base);  // address arithmetic only: the host never dereferences it
+    PathPool& P = D.noalloc_pool;
+    P.ray[0] = L->ray; P.ray[1] = L->ray + CHIP_NOALLOC_PATHS;
+    P.st[0] = L->st; P.st[1] = L->st + CHIP_NOALLOC_PATHS;
+    P.hit = L->hit; P.sample = L->sample; P.q_lit = L->qlit;
+    P.counters = L->counters; P.errflag = L->err; P.stats = L->stats; P.ovf = L->ovf;
+    P.cap = CHIP_NOALLOC_PATHS;
+  }
+  D.res_ready = true;
+  return 0;
+}
+
 // Makes pool `which` hold min(want_paths, max_paths, what fits in free device memory) path slots.
-static int ensure_pool(chip_scene* s, int which, size_t want_paths, size_t max_paths) {
-  chip_scene::PoolBufs& pb = s->pools[which];
+static int ensure_pool(const chip_scene* s, DeviceState& D, int which, size_t want_paths, size_t max_paths) {
+  PoolBufs& pb = D.pools[which];
   uint32_t rows = s->host.cam.max_depth + 2;
   size_t cap = std::min(std::max<size_t>(want_paths, 4096), std::max<size_t>(max_paths, 4096));
   if (!(pb.ready && pb.P.cap >= cap)) {
@@ -163,20 +296,13 @@ static int ensure_pool(chip_scene* s, int which, size_t want_paths, size_t max_p
     if (pb.ready) free_b += (size_t)pb.P.cap * kBytesPerPathSlot;
     cap = std::min(cap, std::max<size_t>(4096, (size_t)(0.8 * (double)free_b) / kBytesPerPathSlot));
   }
-  if (!s->h_pinned) {
-    HIP_TRY(s->p_err.alloc(4));
-    HIP_TRY(s->p_stats.alloc(4));
-    HIP_TRY(hipHostMalloc((void**)&s->h_pinned, 64 * sizeof(uint32_t), hipHostMallocDefault));
-  }
+  if (ensure_resources(D)) return -1;
   if (pb.ready && pb.P.cap >= cap && pb.counters_rows >= rows) return 0;
-  if (!pb.ready) {
-    HIP_TRY(pb.ovf.alloc((size_t)kMaxGridBlocks * CHIP_BLOCK * CHIP_STACK_OVF * 2));
-    HIP_TRY(hipHostMalloc((void**)&pb.h_live, 16 * sizeof(uint32_t), hipHostMallocDefault));
-    HIP_TRY(hipStreamCreateWithFlags(&pb.stream, hipStreamNonBlocking));
-  }
+  if (!pb.ready) HIP_TRY(pb.ovf.alloc((size_t)kMaxGridBlocks * CHIP_BLOCK * CHIP_STACK_OVF * 2));
   if (!pb.ready || pb.P.cap < cap) {
     pb.ray.release(); pb.hit.release(); pb.st.release(); pb.sample.release();
     pb.qlit.release();
+    pb.ready = false;
     HIP_TRY(pb.ray.alloc(2 * cap));
     HIP_TRY(pb.hit.alloc(cap));
     HIP_TRY(pb.st.alloc(2 * cap));
@@ -191,7 +317,7 @@ static int ensure_pool(chip_scene* s, int which, size_t want_paths, size_t max_p
   PathPool& P = pb.P;
   P.ray[0] = pb.ray.p; P.ray[1] = pb.ray.p + P.cap; P.st[0] = pb.st.p; P.st[1] = pb.st.p + P.cap;
   P.hit = pb.hit.p; P.sample = pb.sample.p; P.q_lit = pb.qlit.p;
-  P.counters = pb.counters.p; P.errflag = s->p_err.p; P.stats = s->p_stats.p; P.ovf = pb.ovf.p;
+  P.counters = pb.counters.p; P.errflag = D.p_err.p; P.stats = D.p_stats.p; P.ovf = pb.ovf.p;
   pb.ready = true;
   return 0;
 }
@@ -213,7 +339,6 @@ static uint32_t grid_for(size_t n) {
 
 struct RenderPlan {
   uint32_t xmin, xmax, ymin, ymax, rw, rh;
-  std::vector<uint32_t> strata;  // not materialised: first, stride, count
   uint32_t s_first, s_stride, s_count;
 };
 
@@ -266,35 +391,33 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
   }
   return p;
 }
-static bool g_launch_shape_error = false;
 template <uint32_t F, bool CACHE, bool ORD, bool B0>
-static void launch_extend_b(const chip_scene* s, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
-                            uint32_t bounce, uint32_t lit_pass) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_extend<F, CACHE, ORD, B0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-    attr_set = true;
+static int launch_extend_b(const DeviceState& D, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
+                           uint32_t bounce, uint32_t lit_pass) {
+  // the instantiation may use all of a CU's LDS: told to the runtime once per device
+  static std::atomic<uint64_t> attr_done{0};
+  const uint64_t bit = 1ull << ((unsigned)D.device & 63u);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_extend<F, CACHE, ORD, B0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    attr_done.fetch_or(bit, std::memory_order_release);
   }
-  if (p.block != (uint32_t)extend_block(F, CACHE)) {  // never launch a shape the instantiation was not compiled for
-    g_launch_shape_error = true;
-    return;
-  }
+  // never launch a shape the instantiation was not compiled for
+  if (p.block != (uint32_t)extend_block(F, CACHE)) return fail("internal: traversal launch planned for another kernel variant");
   uint32_t blocks = (n_live_upper + p.block - 1) / p.block;
-  uint32_t max_blocks = CACHE ? (uint32_t)s->n_cus : kMaxGridBlocksDef;
+  uint32_t max_blocks = CACHE ? (uint32_t)D.n_cus : kMaxGridBlocksDef;
   blocks = std::max(1u, std::min(blocks, max_blocks));
-  hipLaunchKernelGGL((k_extend<F, CACHE, ORD, B0>), dim3(blocks), dim3(p.block), p.lds_bytes, st, s->dscene, P, B, bounce, p.cd, lit_pass);
+  hipLaunchKernelGGL((k_extend<F, CACHE, ORD, B0>), dim3(blocks), dim3(p.block), p.lds_bytes, st, D.dscene, P, B, bounce, p.cd, lit_pass);
+  return 0;
 }
 template <uint32_t F, bool CACHE, bool ORD>
-static void launch_extend_t(const chip_scene* s, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
-                            uint32_t bounce, uint32_t lit_pass) {
-  if (bounce == 0) launch_extend_b<F, CACHE, ORD, true>(s, P, p, n_live_upper, st, B, bounce, lit_pass);
-  else launch_extend_b<F, CACHE, ORD, false>(s, P, p, n_live_upper, st, B, bounce, lit_pass);
+static int launch_extend_t(const DeviceState& D, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
+                           uint32_t bounce, uint32_t lit_pass) {
+  if (bounce == 0) return launch_extend_b<F, CACHE, ORD, true>(D, P, p, n_live_upper, st, B, bounce, lit_pass);
+  return launch_extend_b<F, CACHE, ORD, false>(D, P, p, n_live_upper, st, B, bounce, lit_pass);
 }
-// One bounce of traversal: the ordered traversal followed by a literal pass over the rays it handed back (normally none; all of
-// them in a reference_order render).
-static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B, uint32_t bounce) {
-  // the launch shape (threads per block, LDS split) must be planned for the instantiation that runs, which for a
-  // feature set without a variant of its own is the one with every feature
+// The feature set whose traversal instantiation runs a scene with features `feat`: its own when one was compiled,
+// else the one with every feature.
+static uint32_t extend_variant(uint32_t feat) {
   switch (feat) {
     case 0:
     case TF_QUADS:
@@ -302,24 +425,35 @@ static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat,
     case TF_QUADS | TF_XFORM | TF_NO_QUADROT:
     case TF_QUADS | TF_XFORM | TF_EXT:
     case TF_QUADS | TF_XFORM | TF_MEDIA:
-    case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: break;
-    default: feat = TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT | TF_MEDIA_ANY; break;
+    case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: return feat;
+    default: return TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT | TF_MEDIA_ANY;
   }
+}
+// One bounce of traversal: the ordered traversal followed by a literal pass over the rays it handed back (normally none; all of
+// them in a reference_order render).
+static int launch_extend(const chip_scene* s, const DeviceState& D, const PathPool& P, uint32_t feat, uint32_t n_live_upper, hipStream_t st,
+                         const BatchDesc& B, uint32_t bounce) {
+  // the launch shape (threads per block, LDS split) must be planned for the instantiation that runs
+  feat = extend_variant(feat);
   const ExtendPlan lit = plan_extend(s, feat, true);
   const ExtendPlan p = plan_extend(s, feat, false);
-#define CHIP_EXT(FEAT)                                                                                             \
-  if (p.cache) launch_extend_t<FEAT, true, true>(s, P, p, n_live_upper, st, B, bounce, 0);                         \
-  else launch_extend_t<FEAT, false, true>(s, P, p, n_live_upper, st, B, bounce, 0);                                \
-  launch_extend_t<FEAT, false, false>(s, P, lit, B.reference_order ? n_live_upper : std::min<uint32_t>(n_live_upper, 64u * CHIP_BLOCK), st, B, bounce, 1)
+  const uint32_t lit_upper = B.reference_order ? n_live_upper : std::min<uint32_t>(n_live_upper, 64u * CHIP_BLOCK);
+#define CHIP_EXT(FEAT)                                                                                   \
+  {                                                                                                      \
+    int rc_ = p.cache ? launch_extend_t<FEAT, true, true>(D, P, p, n_live_upper, st, B, bounce, 0)       \
+                      : launch_extend_t<FEAT, false, true>(D, P, p, n_live_upper, st, B, bounce, 0);     \
+    if (rc_) return rc_;                                                                                 \
+    return launch_extend_t<FEAT, false, false>(D, P, lit, lit_upper, st, B, bounce, 1);                  \
+  }
   switch (feat) {
-    case 0: CHIP_EXT(0); break;
-    case TF_QUADS: CHIP_EXT(TF_QUADS); break;
-    case TF_QUADS | TF_XFORM: CHIP_EXT(TF_QUADS | TF_XFORM); break;
-    case TF_QUADS | TF_XFORM | TF_NO_QUADROT: CHIP_EXT(TF_QUADS | TF_XFORM | TF_NO_QUADROT); break;
-    case TF_QUADS | TF_XFORM | TF_EXT: CHIP_EXT(TF_QUADS | TF_XFORM | TF_EXT); break;
-    case TF_QUADS | TF_XFORM | TF_MEDIA: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA); break;
-    case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY); break;
-    default: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT | TF_MEDIA_ANY); break;
+    case 0: CHIP_EXT(0)
+    case TF_QUADS: CHIP_EXT(TF_QUADS)
+    case TF_QUADS | TF_XFORM: CHIP_EXT(TF_QUADS | TF_XFORM)
+    case TF_QUADS | TF_XFORM | TF_NO_QUADROT: CHIP_EXT(TF_QUADS | TF_XFORM | TF_NO_QUADROT)
+    case TF_QUADS | TF_XFORM | TF_EXT: CHIP_EXT(TF_QUADS | TF_XFORM | TF_EXT)
+    case TF_QUADS | TF_XFORM | TF_MEDIA: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA)
+    case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY)
+    default: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT | TF_MEDIA_ANY)
   }
 #undef CHIP_EXT
 }
@@ -330,11 +464,16 @@ static void launch_extend(const chip_scene* s, const PathPool& P, uint32_t feat,
 // bounce by bounce in turn, so the device overlaps the traversal of one batch with the shading of the
 // other.  Batches add their samples to d_sum in batch order (chained events), which keeps the f32 sums
 // independent of how the device interleaved them.
-static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPlan& pl, float* d_sum, hipStream_t stream, chip_stats* stats) {
-  HIP_TRY(hipSetDevice(s->device));
-  const DScene& S = s->dscene;
+// With `noalloc` the call uses the device's static scratch pool on the caller's stream (one batch at a time) and
+// the streams, events and pinned words made at commit: it allocates nothing.
+static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o, const RenderPlan& pl, float* d_sum, hipStream_t stream,
+                       chip_stats* stats, bool noalloc) {
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(D.device));
+  if (!D.uploaded) return fail("scene not committed on this device");
+  const DScene& S = D.dscene;
   const DCamera& cam = s->host.cam;
-  const bool time_kernels = (o->flags & CHIP_RENDER_TIME_KERNELS) != 0;
+  const bool time_kernels = !noalloc && (o->flags & CHIP_RENDER_TIME_KERNELS) != 0;
   const bool exact_shading = (o->flags & CHIP_RENDER_EXACT_SHADING) != 0;
   const uint32_t feat = scene_features(s->flat);
   // spheres with solid colours and no light sampling: the lean shade kernels
@@ -345,21 +484,32 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
   const bool lean_xform = solid_only && (feat & ~TF_NO_QUADROT) == (TF_QUADS | TF_XFORM) && s->flat.quads.empty() && s->flat.media.empty();
 
   // pools: two when the render is large enough to be worth splitting
-  const size_t want_total = (size_t)pl.rw * pl.rh * std::max<uint32_t>(pl.s_count, 1);
-  const char* e_streams = getenv("CHIP_STREAMS");
-  size_t overlap_min = (size_t)1 << 24;  // renders smaller than this are not worth splitting
-  if (const char* e_min = getenv("CHIP_OVERLAP_MIN_PATHS")) overlap_min = (size_t)std::max<long long>(0, atoll(e_min));
-  int lanes_wanted = 2;  // batches in flight (CHIP_STREAMS overrides: 1 = no overlap)
-  if (e_streams && *e_streams) lanes_wanted = std::max(1, std::min(chip_scene::kMaxLanes, atoi(e_streams)));
-  if (want_total < overlap_min) lanes_wanted = 1;
-  const int n_lanes = (int)std::min<uint32_t>((uint32_t)lanes_wanted, std::max<uint32_t>(pl.s_count, 1));
-  const size_t max_each = pool_capacity_max() / (size_t)n_lanes;
-  const size_t want_each = (size_t)pl.rw * pl.rh * ((std::max<uint32_t>(pl.s_count, 1) + n_lanes - 1) / n_lanes);
-  for (int k = 0; k < n_lanes; k++)
-    if (ensure_pool(s, k, want_each, max_each)) return -1;
-  size_t cap = s->pools[0].P.cap;
-  for (int k = 1; k < n_lanes; k++) cap = std::min<size_t>(cap, s->pools[k].P.cap);
-  if (pl.rw > cap) return fail("render rectangle is wider than the path pool");
+  int n_lanes = 1;
+  size_t cap = 0;
+  if (noalloc) {
+    if (!D.res_ready || !D.noalloc_base) return fail("scene not committed on this device");
+    if (cam.max_depth + 2 > CHIP_NOALLOC_COUNTER_ROWS) return fail("max_depth is beyond what the no-allocation entry point supports (254)");
+    if ((size_t)pl.rw * pl.rh > CHIP_NOALLOC_PATHS) return fail("render rectangle holds more pixels than the no-allocation entry point supports (32768)");
+    cap = CHIP_NOALLOC_PATHS;
+  } else {
+    const size_t want_total = (size_t)pl.rw * pl.rh * std::max<uint32_t>(pl.s_count, 1);
+    const char* e_streams = getenv("CHIP_STREAMS");
+    size_t overlap_min = (size_t)1 << 24;  // renders smaller than this are not worth splitting
+    if (const char* e_min = getenv("CHIP_OVERLAP_MIN_PATHS")) overlap_min = (size_t)std::max<long long>(0, atoll(e_min));
+    int lanes_wanted = 2;  // batches in flight (CHIP_STREAMS overrides: 1 = no overlap)
+    if (e_streams && *e_streams) lanes_wanted = std::max(1, std::min(kMaxLanes, atoi(e_streams)));
+    if (want_total < overlap_min) lanes_wanted = 1;
+    n_lanes = (int)std::min<uint32_t>((uint32_t)lanes_wanted, std::max<uint32_t>(pl.s_count, 1));
+    const size_t max_each = pool_capacity_max() / (size_t)n_lanes;
+    const size_t want_each = (size_t)pl.rw * pl.rh * ((std::max<uint32_t>(pl.s_count, 1) + n_lanes - 1) / n_lanes);
+    for (int k = 0; k < n_lanes; k++)
+      if (ensure_pool(s, D, k, want_each, max_each)) return -1;
+    cap = D.pools[0].P.cap;
+    for (int k = 1; k < n_lanes; k++) cap = std::min<size_t>(cap, D.pools[k].P.cap);
+    if (pl.rw > cap) return fail("render rectangle is wider than the path pool");
+  }
+  uint32_t* const d_err = noalloc ? D.noalloc_pool.errflag : D.p_err.p;
+  unsigned long long* const d_stats = noalloc ? D.noalloc_pool.stats : D.p_stats.p;
 
   // batches: bands of rows (only when one stratum of the rectangle exceeds a pool) x groups of strata
   struct Batch {
@@ -387,14 +537,15 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
       B.n_paths = npix * B.n_strata;
       B.seed_lo = (uint32_t)o->seed;
       B.seed_hi = (uint32_t)(o->seed >> 32);
-      B.reference_order = ((o->flags & CHIP_RENDER_REFERENCE_ORDER) || s->dscene.literal_only) ? 1u : 0u;
+      B.reference_order = ((o->flags & CHIP_RENDER_REFERENCE_ORDER) || S.literal_only) ? 1u : 0u;
       bt.by = by;
       batches.push_back(bt);
     }
   }
 
   struct Lane {
-    chip_scene::PoolBufs* pb = nullptr;
+    const PathPool* P = nullptr;
+    LaneRes* res = nullptr;
     hipStream_t st = nullptr;
     bool active = false;
     bool traced = false;  // all bounces of the batch are enqueued; only the accumulation is still to come
@@ -402,29 +553,31 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
     uint32_t bounce = 0, live_upper = 0;
     // live-count readbacks in flight: the host runs ahead of the device and only learns a bounce's live
     // count (which sizes later grids and ends the batch early) when the copy has landed
-    hipEvent_t ev_rb[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t rb_head = 0, rb_count = 0;
     std::vector<hipEvent_t> kev;  // (trace begin, trace end = shade begin, shade end) per bounce
   };
-  Lane lanes[chip_scene::kMaxLanes];
+  Lane lanes[kMaxLanes];
   const bool forked = n_lanes >= 2 && batches.size() >= 2;
   const int n_active_lanes = forked ? (int)std::min<size_t>((size_t)n_lanes, batches.size()) : 1;
-  hipEvent_t ev0, ev1, ev_fork = nullptr;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
-  std::vector<hipEvent_t> ev_acc(batches.size(), nullptr);  // batch i has added its samples to d_sum
-  HIP_TRY(hipMemsetAsync(s->p_err.p, 0, 4 * sizeof(uint32_t), stream));
-  HIP_TRY(hipMemsetAsync(s->p_stats.p, 0, 4 * sizeof(unsigned long long), stream));
-  HIP_TRY(hipEventRecord(ev0, stream));
-  if (forked) {
-    HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(ev_fork, stream));
-  }
+  EventBag bag;  // events of this call only (kernel timing, batch-order chain)
+#define RENDER_TRY(expr)                                                                        \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      bag.failed = true;                                                                        \
+      return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+    }                                                                                           \
+  } while (0)
+  std::vector<hipEvent_t> ev_acc(forked ? batches.size() : 0, nullptr);  // batch i has added its samples to d_sum
+  RENDER_TRY(hipMemsetAsync(d_err, 0, 4 * sizeof(uint32_t), stream));
+  RENDER_TRY(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), stream));
+  RENDER_TRY(hipEventRecord(D.ev0, stream));
+  if (forked) RENDER_TRY(hipEventRecord(D.ev_fork, stream));
   for (int k = 0; k < n_active_lanes; k++) {
-    lanes[k].pb = &s->pools[k];
-    lanes[k].st = forked ? s->pools[k].stream : stream;
-    if (forked) HIP_TRY(hipStreamWaitEvent(lanes[k].st, ev_fork, 0));
-    for (int j = 0; j < 4; j++) HIP_TRY(hipEventCreateWithFlags(&lanes[k].ev_rb[j], hipEventDisableTiming));
+    lanes[k].P = noalloc ? &D.noalloc_pool : &D.pools[k].P;
+    lanes[k].res = &D.lanes[k];
+    lanes[k].st = forked ? D.lanes[k].stream : stream;
+    if (forked) RENDER_TRY(hipStreamWaitEvent(lanes[k].st, D.ev_fork, 0));
   }
   uint64_t n_paths_total = 0, n_trace_launches = 0;
   size_t next_batch = 0;
@@ -434,12 +587,14 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
     // the sums take the batches in order: a batch whose predecessor (on another stream) has not been
     // enqueued to its end yet waits on the host and is asked again on the next round
     L.traced = true;
-    if (L.batch > 0 && !ev_acc[L.batch - 1]) return 0;
-    if (L.batch > 0) HIP_TRY(hipStreamWaitEvent(L.st, ev_acc[L.batch - 1], 0));
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(bt.B.npix)), dim3(CHIP_BLOCK), 0, L.st, L.pb->P, bt.B, d_sum + (size_t)bt.by * pl.rw * 3);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventCreateWithFlags(&ev_acc[L.batch], hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(ev_acc[L.batch], L.st));
+    if (forked && L.batch > 0 && !ev_acc[L.batch - 1]) return 0;
+    if (forked && L.batch > 0) RENDER_TRY(hipStreamWaitEvent(L.st, ev_acc[L.batch - 1], 0));
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(bt.B.npix)), dim3(CHIP_BLOCK), 0, L.st, *L.P, bt.B, d_sum + (size_t)bt.by * pl.rw * 3);
+    RENDER_TRY(hipGetLastError());
+    if (forked) {
+      RENDER_TRY(bag.make(&ev_acc[L.batch], false));
+      RENDER_TRY(hipEventRecord(ev_acc[L.batch], L.st));
+    }
     L.active = false;
     L.traced = false;
     return 0;
@@ -453,20 +608,23 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
   auto advance = [&](Lane& L) -> int {
     const Batch& bt = batches[L.batch];
     const BatchDesc& B = bt.B;
-    const PathPool& P = L.pb->P;
-    auto new_event = [&]() {
+    const PathPool& P = *L.P;
+    auto stamp = [&]() -> int {
       hipEvent_t e;
-      (void)hipEventCreate(&e);
+      RENDER_TRY(bag.make(&e, true));
       L.kev.push_back(e);
-      return e;
+      RENDER_TRY(hipEventRecord(e, L.st));
+      return 0;
     };
     while (L.bounce < cam.max_depth) {
       const uint32_t bounce = L.bounce;
       const uint32_t grid = std::min(grid_for(L.live_upper), shade_grid_max);
-      if (time_kernels) (void)hipEventRecord(new_event(), L.st);
-      launch_extend(s, P, feat, L.live_upper, L.st, B, bounce);
-      if (g_launch_shape_error) return fail("internal: traversal launch planned for another kernel variant");
-      if (time_kernels) (void)hipEventRecord(new_event(), L.st);
+      if (time_kernels && stamp()) return -1;
+      if (launch_extend(s, D, P, feat, L.live_upper, L.st, B, bounce)) {
+        bag.failed = true;
+        return -1;
+      }
+      if (time_kernels && stamp()) return -1;
       n_trace_launches++;
       {
         const bool ext = (feat & TF_EXT) != 0;
@@ -486,13 +644,13 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
         }
 #undef CHIP_SHADE
       }
-      if (time_kernels) (void)hipEventRecord(new_event(), L.st);
+      if (time_kernels && stamp()) return -1;
       L.bounce++;
       // every few bounces learn how many paths are still alive (sizes the grids, stops the loop early)
       if (L.bounce < cam.max_depth && (bounce % 4) == 3) {
         const uint32_t j = (L.rb_head + L.rb_count) % 4;
-        HIP_TRY(hipMemcpyAsync(L.pb->h_live + j, P.counters + (size_t)L.bounce * CHIP_CTR_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToHost, L.st));
-        HIP_TRY(hipEventRecord(L.ev_rb[j], L.st));
+        RENDER_TRY(hipMemcpyAsync(L.res->h_live + j, P.counters + (size_t)L.bounce * CHIP_CTR_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToHost, L.st));
+        RENDER_TRY(hipEventRecord(L.res->ev_rb[j], L.st));
         L.rb_count++;
         return 0;
       }
@@ -504,24 +662,23 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
     while (L.rb_count) {
       const uint32_t j = L.rb_head;
       if (must || L.rb_count >= 3) {
-        HIP_TRY(hipEventSynchronize(L.ev_rb[j]));
+        RENDER_TRY(hipEventSynchronize(L.res->ev_rb[j]));
       } else {
-        hipError_t q = hipEventQuery(L.ev_rb[j]);
+        hipError_t q = hipEventQuery(L.res->ev_rb[j]);
         if (q == hipErrorNotReady) break;
-        HIP_TRY(q);
+        RENDER_TRY(q);
       }
       must = false;
-      L.live_upper = std::min(L.live_upper, L.pb->h_live[j]);
+      L.live_upper = std::min(L.live_upper, L.res->h_live[j]);
       L.rb_head = (L.rb_head + 1) % 4;
       L.rb_count--;
     }
     return 0;
   };
 
-  int rc = 0;
   for (;;) {
     bool any = false;
-    for (int k = 0; k < n_active_lanes && rc == 0; k++) {
+    for (int k = 0; k < n_active_lanes; k++) {
       Lane& L = lanes[k];
       if (!L.active) {
         if (next_batch >= batches.size()) continue;
@@ -529,74 +686,57 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
         L.active = true;
         L.bounce = 0;
         const Batch& bt = batches[L.batch];
-        const PathPool& P = L.pb->P;
+        const PathPool& P = *L.P;
         n_paths_total += bt.B.n_paths;
-        rc = hipMemsetAsync(P.counters, 0, (size_t)L.pb->counters_rows * CHIP_CTR_STRIDE * sizeof(uint32_t), L.st) == hipSuccess ? 0 : fail("hipMemsetAsync failed");
-        if (rc) break;
+        RENDER_TRY(hipMemsetAsync(P.counters, 0, (size_t)(cam.max_depth + 2) * CHIP_CTR_STRIDE * sizeof(uint32_t), L.st));
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, L.st, P, bt.B);
         // a path writes its sample when it ends; with max_depth 0 no path ever starts (camera.rs:259-261)
-        if (cam.max_depth == 0) (void)hipMemsetAsync(P.sample, 0, (size_t)bt.B.n_paths * sizeof(float4), L.st);
+        if (cam.max_depth == 0) RENDER_TRY(hipMemsetAsync(P.sample, 0, (size_t)bt.B.n_paths * sizeof(float4), L.st));
         L.live_upper = bt.B.n_paths;
       }
       any = true;
-      rc = poll_readbacks(L, false);
-      if (rc) break;
-      if (L.traced || L.live_upper == 0) rc = finish_batch(L);
-      else rc = advance(L);
-      if (rc == 0 && !L.active) {  // the batch is fully enqueued: its readbacks are of no further use
+      if (poll_readbacks(L, false)) return -1;
+      if (L.traced || L.live_upper == 0) {
+        if (finish_batch(L)) return -1;
+      } else if (advance(L)) {
+        return -1;
+      }
+      if (!L.active) {  // the batch is fully enqueued: its readbacks are of no further use
+        // (a copy still in flight lands before the next batch's copy into the same slot: one stream, in order)
         L.rb_head = 0;
         L.rb_count = 0;
       }
     }
-    if (rc || !any) break;
+    if (!any) break;
   }
-  if (rc == 0 && forked) {
+  if (forked) {
     for (int k = 0; k < n_active_lanes; k++) {
-      hipEvent_t e;
-      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      HIP_TRY(hipEventRecord(e, lanes[k].st));
-      HIP_TRY(hipStreamWaitEvent(stream, e, 0));
-      ev_acc.push_back(e);
+      RENDER_TRY(hipEventRecord(lanes[k].res->ev_join, lanes[k].st));
+      RENDER_TRY(hipStreamWaitEvent(stream, lanes[k].res->ev_join, 0));
     }
   }
-  if (rc == 0) {
-    HIP_TRY(hipEventRecord(ev1, stream));
-    HIP_TRY(hipMemcpyAsync(s->h_pinned + 8, s->p_err.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(s->h_pinned + 16, s->p_stats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipGetLastError());
-  } else {
-    (void)hipDeviceSynchronize();
-  }
+  RENDER_TRY(hipEventRecord(D.ev1, stream));
+  RENDER_TRY(hipMemcpyAsync(D.h_pinned + 8, d_err, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  RENDER_TRY(hipMemcpyAsync(D.h_pinned + 16, d_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+  RENDER_TRY(hipStreamSynchronize(stream));
+  RENDER_TRY(hipGetLastError());
   float ms = 0.f;
   double ms_trace = 0.0, ms_shade = 0.0;
-  if (rc == 0) {
-    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    for (int k = 0; k < n_active_lanes; k++) {
-      const std::vector<hipEvent_t>& kev = lanes[k].kev;
-      for (size_t i = 0; i + 2 < kev.size(); i += 3) {
-        float a = 0.f, b = 0.f;
-        (void)hipEventElapsedTime(&a, kev[i], kev[i + 1]);
-        (void)hipEventElapsedTime(&b, kev[i + 1], kev[i + 2]);
-        ms_trace += a;
-        ms_shade += b;
-      }
+  RENDER_TRY(hipEventElapsedTime(&ms, D.ev0, D.ev1));
+  for (int k = 0; k < n_active_lanes; k++) {
+    const std::vector<hipEvent_t>& kev = lanes[k].kev;
+    for (size_t i = 0; i + 2 < kev.size(); i += 3) {
+      float a = 0.f, b = 0.f;
+      (void)hipEventElapsedTime(&a, kev[i], kev[i + 1]);
+      (void)hipEventElapsedTime(&b, kev[i + 1], kev[i + 2]);
+      ms_trace += a;
+      ms_shade += b;
     }
   }
-  for (int k = 0; k < n_active_lanes; k++) {
-    for (hipEvent_t e : lanes[k].kev) (void)hipEventDestroy(e);
-    for (int j = 0; j < 4; j++)
-      if (lanes[k].ev_rb[j]) (void)hipEventDestroy(lanes[k].ev_rb[j]);
-  }
-  for (hipEvent_t e : ev_acc)
-    if (e) (void)hipEventDestroy(e);
-  if (ev_fork) (void)hipEventDestroy(ev_fork);
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
-  if (rc) return rc;
-  if (s->h_pinned[8] & 1u) return fail("traversal stack overflow (scene nesting deeper than the device stack)");
+#undef RENDER_TRY
+  if (D.h_pinned[8] & 1u) return fail("traversal stack overflow (scene nesting deeper than the device stack)");
   if (stats) {
-    const unsigned long long* st = (const unsigned long long*)(s->h_pinned + 16);
+    const unsigned long long* st = (const unsigned long long*)(D.h_pinned + 16);
     stats->paths = n_paths_total;
     stats->segments = st[0];
     stats->bvh_visits = st[1];
@@ -609,6 +749,55 @@ static int render_into(chip_scene* s, const chip_render_opts* o, const RenderPla
     stats->batches = batches.size();
   }
   return 0;
+}
+
+// Flattened tables -> device `D.device` (current on entry).
+static int upload_scene(chip_scene* s, DeviceState& D, const Flat& F) {
+  D.uploaded = false;
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, D.device));
+    D.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (ensure_resources(D)) return -1;
+  HIP_TRY(D.d_bvh.upload(F.bvh));
+  HIP_TRY(D.d_tnodes.upload(F.tnodes));
+  HIP_TRY(D.d_spheres.upload(F.spheres));
+  HIP_TRY(D.d_quads.upload(F.quads));
+  HIP_TRY(D.d_groups.upload(F.groups));
+  HIP_TRY(D.d_gchild.upload(F.gchild));
+  HIP_TRY(D.d_gbox.upload(F.gbox));
+  HIP_TRY(D.d_translates.upload(F.translates));
+  HIP_TRY(D.d_rotates.upload(F.rotates));
+  HIP_TRY(D.d_scales.upload(F.scales));
+  HIP_TRY(D.d_discs.upload(F.discs));
+  HIP_TRY(D.d_cones.upload(F.cones));
+  HIP_TRY(D.d_media.upload(F.media));
+  HIP_TRY(D.d_xchain.upload(F.xchain));
+  HIP_TRY(D.d_materials.upload(s->host.materials));
+  HIP_TRY(D.d_textures.upload(s->host.textures));
+  HIP_TRY(D.d_perlins.upload(s->host.perlins));
+  HIP_TRY(D.d_texels.upload(s->host.texels));
+  HIP_TRY(D.d_lights.upload(F.lights));
+  DScene& T = D.dscene;
+  T.bvh = D.d_bvh.p; T.tnodes = D.d_tnodes.p; T.spheres = D.d_spheres.p; T.quads = D.d_quads.p; T.groups = D.d_groups.p; T.gchild = D.d_gchild.p; T.gbox = D.d_gbox.p;
+  T.translates = D.d_translates.p; T.rotates = D.d_rotates.p; T.scales = D.d_scales.p; T.discs = D.d_discs.p; T.cones = D.d_cones.p;
+  T.media = D.d_media.p; T.xchain = D.d_xchain.p;
+  T.materials = D.d_materials.p; T.textures = D.d_textures.p; T.perlins = D.d_perlins.p; T.texels = D.d_texels.p;
+  T.lights = D.d_lights.p;
+  T.root = F.root;
+  T.n_lights = (uint32_t)F.lights.size();
+  T.has_lights = F.has_lights;
+  T.lights_is_group = F.lights_is_group;
+  T.literal_only = F.loose_geometry;
+  T.cam = s->host.cam;
+  D.uploaded = true;
+  return 0;
+}
+
+// a += b over n floats (the sums of another GPU added to this one's)
+__global__ void __launch_bounds__(CHIP_BLOCK) k_add_sums(float* a, const float* b, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i];
 }
 
 extern "C" {
@@ -950,34 +1139,14 @@ int chip_scene_set_camera(chip_scene* s, const chip_camera_desc* d) {
 
 int chip_commit(chip_scene* s) {
   NEED_SCENE;
+  s->committed = false;  // a commit that fails midway leaves the scene uncommitted, not pointing at freed tables
   Flat F;
   try {
     s->host.flatten(F);
   } catch (const std::exception& e) {
     return fail(e.what());
   }
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  s->device = dev;
-  {
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  HIP_TRY(s->d_bvh.upload(F.bvh));
-  HIP_TRY(s->d_tnodes.upload(F.tnodes));
-  HIP_TRY(s->d_spheres.upload(F.spheres));
-  HIP_TRY(s->d_quads.upload(F.quads));
-  HIP_TRY(s->d_groups.upload(F.groups));
-  HIP_TRY(s->d_gchild.upload(F.gchild));
-  HIP_TRY(s->d_gbox.upload(F.gbox));
-  HIP_TRY(s->d_translates.upload(F.translates));
-  HIP_TRY(s->d_rotates.upload(F.rotates));
-  HIP_TRY(s->d_scales.upload(F.scales));
-  HIP_TRY(s->d_discs.upload(F.discs));
-  HIP_TRY(s->d_cones.upload(F.cones));
-  HIP_TRY(s->d_media.upload(F.media));
-  HIP_TRY(s->d_xchain.upload(F.xchain));
+  if (F.has_lights && F.lights.empty() && !F.lights_is_group) return fail("internal: empty light list");
   // a material needs (u, v) only when an image texture is reachable from its texture (checker sub-textures included)
   {
     const std::vector<DTexture>& T = s->host.textures;
@@ -997,26 +1166,58 @@ int chip_commit(chip_scene* s) {
         for (int c = 0; c < 3; c++) m.p[c] = T[m.tex].p[c];
     }
   }
-  HIP_TRY(s->d_materials.upload(s->host.materials));
-  HIP_TRY(s->d_textures.upload(s->host.textures));
-  HIP_TRY(s->d_perlins.upload(s->host.perlins));
-  HIP_TRY(s->d_texels.upload(s->host.texels));
-  if (F.has_lights && F.lights.empty() && !F.lights_is_group) return fail("internal: empty light list");
-  HIP_TRY(s->d_lights.upload(F.lights));
-  DScene& D = s->dscene;
-  D.bvh = s->d_bvh.p; D.tnodes = s->d_tnodes.p; D.spheres = s->d_spheres.p; D.quads = s->d_quads.p; D.groups = s->d_groups.p; D.gchild = s->d_gchild.p; D.gbox = s->d_gbox.p;
-  D.translates = s->d_translates.p; D.rotates = s->d_rotates.p; D.scales = s->d_scales.p; D.discs = s->d_discs.p; D.cones = s->d_cones.p;
-  D.media = s->d_media.p; D.xchain = s->d_xchain.p;
-  D.materials = s->d_materials.p; D.textures = s->d_textures.p; D.perlins = s->d_perlins.p; D.texels = s->d_texels.p;
-  D.lights = s->d_lights.p;
-  D.root = F.root;
-  D.n_lights = (uint32_t)F.lights.size();
-  D.has_lights = F.has_lights;
-  D.lights_is_group = F.lights_is_group;
-  D.literal_only = F.loose_geometry;
-  D.cam = s->host.cam;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  // replicas made by an earlier chip_commit_devices describe the previous scene
+  if (!s->replicas.empty()) {
+    DeviceGuard guard;
+    for (auto& r : s->replicas)
+      if (r && r->device >= 0 && hipSetDevice(r->device) == hipSuccess) r->release_all();
+    s->replicas.clear();
+  }
+  // committing under another current device than last time: what was made on the old device goes
+  if (s->dev.device >= 0 && s->dev.device != dev) {
+    DeviceGuard guard;
+    if (hipSetDevice(s->dev.device) == hipSuccess) s->dev.release_all();
+  }
+  s->dev.device = dev;
+  if (upload_scene(s, s->dev, F)) return -1;
   s->flat = std::move(F);
   s->committed = true;
+  return 0;
+}
+
+int chip_commit_devices(chip_scene* s, const int* devices, int n) {
+  NEED_SCENE;
+  if (!s->committed) return fail("chip_commit_devices: commit the scene first");
+  if (n < 1 || n > 64 || !devices) return fail("chip_commit_devices: need 1 to 64 devices");
+  int count = 0;
+  HIP_TRY(hipGetDeviceCount(&count));
+  for (int i = 0; i < n; i++)
+    if (devices[i] < 0 || devices[i] >= count) return fail("chip_commit_devices: no such device");
+  DeviceGuard guard;
+  for (auto& r : s->replicas)
+    if (r && r->device >= 0 && hipSetDevice(r->device) == hipSuccess) r->release_all();
+  s->replicas.clear();
+  for (int i = 0; i < n; i++) {
+    std::unique_ptr<DeviceState> r(new DeviceState());
+    r->device = devices[i];
+    HIP_TRY(hipSetDevice(devices[i]));
+    int rc = upload_scene(s, *r, s->flat);
+    s->replicas.push_back(std::move(r));  // (kept also when the upload failed: what it allocated is released with the others)
+    if (rc) return -1;
+  }
+  // the sums travel from every replica's device to the first one's: direct peer access where the machine offers it
+  for (int i = 1; i < n; i++) {
+    if (devices[i] == devices[0]) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can) {
+      HIP_TRY(hipSetDevice(devices[0]));
+      hipError_t e = hipDeviceEnablePeerAccess(devices[i], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
+  }
   return 0;
 }
 
@@ -1053,22 +1254,41 @@ int chip_render_accumulate_device(chip_scene* s, const chip_render_opts* opts, f
   if (!opts || !d_sum_rgb) return fail("null argument");
   RenderPlan pl;
   if (plan_render(s, opts, pl)) return -1;
-  return render_into(s, opts, pl, d_sum_rgb, (hipStream_t)stream, stats);
+  return render_into(s, s->dev, opts, pl, d_sum_rgb, (hipStream_t)stream, stats, false);
 }
 
 int chip_resolve_device(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, void* stream) {
   return chip_resolve_device_flags(s, d_sum_rgb, npixels, d_out_gamma, d_out_rgb8, 0, stream);
 }
+static int resolve_on(chip_scene* s, DeviceState& D, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, uint32_t flags,
+                      hipStream_t stream) {
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(D.device));
+  hipLaunchKernelGGL(k_resolve, dim3(grid_for(npixels * 3)), dim3(CHIP_BLOCK), 0, stream, d_sum_rgb, npixels * 3, s->host.cam.pixel_samples_scale,
+                     d_out_gamma, d_out_rgb8, (flags & CHIP_RENDER_QUANTISE_255) ? 255.0 : 255.999);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(stream));
+  return 0;
+}
 int chip_resolve_device_flags(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, uint32_t flags,
                               void* stream) {
   NEED_SCENE;
   if (!s->host.has_camera) return fail("scene has no camera");
+  if (!s->committed) return fail("scene not committed");
   if (!d_sum_rgb) return fail("null argument");
-  HIP_TRY(hipSetDevice(s->device));
-  hipLaunchKernelGGL(k_resolve, dim3(grid_for(npixels * 3)), dim3(CHIP_BLOCK), 0, (hipStream_t)stream, d_sum_rgb, npixels * 3,
-                     s->host.cam.pixel_samples_scale, d_out_gamma, d_out_rgb8, (flags & CHIP_RENDER_QUANTISE_255) ? 255.0 : 255.999);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return resolve_on(s, s->dev, d_sum_rgb, npixels, d_out_gamma, d_out_rgb8, flags, (hipStream_t)stream);
+}
+
+// The sums of `D` (device buffer, npix * 3 floats) to the host and / or resolved to 8 bits.
+static int frame_outputs(chip_scene* s, DeviceState& D, size_t npix, uint32_t flags, float* out_sum_rgb, uint8_t* out_rgb8) {
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(D.device));
+  if (out_sum_rgb) HIP_TRY(hipMemcpy(out_sum_rgb, D.frame_sum.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  if (out_rgb8) {
+    HIP_TRY(D.frame_rgb8.reserve(npix * 3));
+    if (resolve_on(s, D, D.frame_sum.p, npix, nullptr, D.frame_rgb8.p, flags, nullptr)) return -1;
+    HIP_TRY(hipMemcpy(out_rgb8, D.frame_rgb8.p, npix * 3, hipMemcpyDeviceToHost));
+  }
   return 0;
 }
 
@@ -1077,28 +1297,78 @@ int chip_render_frame(chip_scene* s, const chip_render_opts* opts, float* out_su
   if (!opts) return fail("null argument");
   RenderPlan pl;
   if (plan_render(s, opts, pl)) return -1;
-  HIP_TRY(hipSetDevice(s->device));
-  size_t npix = (size_t)pl.rw * pl.rh;
-  DevBuf<float> d_sum;
-  DevBuf<uint8_t> d_rgb8;
-  HIP_TRY(d_sum.alloc(npix * 3));
-  HIP_TRY(hipMemset(d_sum.p, 0, npix * 3 * sizeof(float)));
-  int rc = render_into(s, opts, pl, d_sum.p, nullptr, stats);
-  if (rc == 0 && out_sum_rgb) {
-    hipError_t e = hipMemcpy(out_sum_rgb, d_sum.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = fail(std::string("hipMemcpy: ") + hipGetErrorString(e));
+  DeviceState& D = s->dev;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(D.device));
+  const size_t npix = (size_t)pl.rw * pl.rh;
+  HIP_TRY(D.frame_sum.reserve(npix * 3));  // kept between calls (grows only)
+  HIP_TRY(hipMemsetAsync(D.frame_sum.p, 0, npix * 3 * sizeof(float), nullptr));
+  if (render_into(s, D, opts, pl, D.frame_sum.p, nullptr, stats, false)) return -1;
+  return frame_outputs(s, D, npix, opts->flags, out_sum_rgb, out_rgb8);
+}
+
+int chip_render_frame_multi(chip_scene* s, const chip_render_opts* opts, float* out_sum_rgb, uint8_t* out_rgb8, chip_stats* stats) {
+  NEED_SCENE;
+  if (!opts) return fail("null argument");
+  const int n = (int)s->replicas.size();
+  if (n < 1) return fail("chip_render_frame_multi: call chip_commit_devices first");
+  RenderPlan pl;
+  if (plan_render(s, opts, pl)) return -1;
+  const size_t npix = (size_t)pl.rw * pl.rh;
+  const uint32_t stride0 = opts->stratum_stride ? opts->stratum_stride : 1;
+  DeviceGuard guard;
+  // replica g takes every n-th of the strata this call covers (crates/cli/src/main.rs:119-163 deals blocks of
+  // pixels to threads; the samples of a pixel are just as independent, camera.rs:335-341)
+  std::vector<int> rc((size_t)n, 0);
+  std::vector<std::string> err((size_t)n);
+  std::vector<chip_stats> st((size_t)n);
+  for (int g = 0; g < n; g++) {
+    DeviceState& D = *s->replicas[(size_t)g];
+    HIP_TRY(hipSetDevice(D.device));
+    HIP_TRY(D.frame_sum.reserve(npix * 3));
+    HIP_TRY(hipMemsetAsync(D.frame_sum.p, 0, npix * 3 * sizeof(float), nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
   }
-  if (rc == 0 && out_rgb8) {
-    hipError_t e = d_rgb8.alloc(npix * 3);
-    if (e == hipSuccess) {
-      rc = chip_resolve_device_flags(s, d_sum.p, npix, nullptr, d_rgb8.p, opts->flags, nullptr);
-      if (rc == 0) e = hipMemcpy(out_rgb8, d_rgb8.p, npix * 3, hipMemcpyDeviceToHost);
+  std::vector<std::thread> workers;
+  for (int g = 0; g < n; g++)
+    workers.emplace_back([&, g]() {
+      chip_render_opts o = *opts;
+      o.stratum_offset = opts->stratum_offset + (uint32_t)g * stride0;
+      o.stratum_stride = stride0 * (uint32_t)n;
+      RenderPlan plg;
+      DeviceState& D = *s->replicas[(size_t)g];
+      rc[(size_t)g] = plan_render(s, &o, plg);
+      if (rc[(size_t)g] == 0) rc[(size_t)g] = render_into(s, D, &o, plg, D.frame_sum.p, D.lanes[kMaxLanes - 1].stream, &st[(size_t)g], false);
+      if (rc[(size_t)g]) err[(size_t)g] = g_err;  // (the message lives in this thread)
+    });
+  for (std::thread& t : workers) t.join();
+  for (int g = 0; g < n; g++)
+    if (rc[(size_t)g]) return fail("replica " + std::to_string(g) + ": " + err[(size_t)g]);
+  // sums of replicas 1 .. n-1 onto replica 0's device, added in replica order (so the result does not depend on timing)
+  DeviceState& D0 = *s->replicas[0];
+  HIP_TRY(hipSetDevice(D0.device));
+  if (n > 1) HIP_TRY(D0.frame_stage.reserve(npix * 3));
+  for (int g = 1; g < n; g++) {
+    DeviceState& D = *s->replicas[(size_t)g];
+    const float* src = D.frame_sum.p;
+    if (D.device != D0.device) {
+      HIP_TRY(hipMemcpyPeerAsync(D0.frame_stage.p, D0.device, D.frame_sum.p, D.device, npix * 3 * sizeof(float), nullptr));
+      src = D0.frame_stage.p;
     }
-    if (e != hipSuccess) rc = fail(std::string("rgb8 output: ") + hipGetErrorString(e));
+    hipLaunchKernelGGL(k_add_sums, dim3(grid_for(npix * 3)), dim3(CHIP_BLOCK), 0, nullptr, D0.frame_sum.p, src, npix * 3);
+    HIP_TRY(hipGetLastError());
   }
-  d_sum.release();
-  d_rgb8.release();
-  return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  if (stats) {
+    *stats = st[0];
+    for (int g = 1; g < n; g++) {
+      stats->paths += st[(size_t)g].paths; stats->segments += st[(size_t)g].segments; stats->bvh_visits += st[(size_t)g].bvh_visits;
+      stats->prim_tests += st[(size_t)g].prim_tests; stats->trace_launches += st[(size_t)g].trace_launches; stats->batches += st[(size_t)g].batches;
+      stats->ms_total = std::max(stats->ms_total, st[(size_t)g].ms_total);
+      stats->ms_trace += st[(size_t)g].ms_trace; stats->ms_shade += st[(size_t)g].ms_shade;
+    }
+  }
+  return frame_outputs(s, D0, npix, opts->flags, out_sum_rgb, out_rgb8);
 }
 
 int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, const double* d, const double* tm, chip_hit* out) {
@@ -1108,8 +1378,10 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
   if (!o || !d || !out) return fail("null argument");
   if (n > 0xFFFFFFFFull) return fail("too many rays");
   static_assert(sizeof(chip_hit) == sizeof(DHitOut), "hit layout");
-  HIP_TRY(hipSetDevice(s->device));
-  if (ensure_pool(s, 0, 0, 4096)) return -1;
+  DeviceState& D = s->dev;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(D.device));
+  if (ensure_pool(s, D, 0, 0, 4096)) return -1;
   DevBuf<double> d_o, d_d, d_t;
   DevBuf<DHitOut> d_out;
   int rc = 0;
@@ -1124,11 +1396,11 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
       if ((e = d_t.alloc(n)) != hipSuccess) break;
       if ((e = hipMemcpy(d_t.p, tm, n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
     }
-    if ((e = hipMemset(s->p_err.p, 0, 4 * sizeof(uint32_t))) != hipSuccess) break;
+    if ((e = hipMemset(D.p_err.p, 0, 4 * sizeof(uint32_t))) != hipSuccess) break;
 #define CHIP_TRACE(FEAT)                                                                                                         \
-  hipLaunchKernelGGL(k_trace_rays<FEAT>, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, s->dscene, s->pools[0].P, (uint32_t)seed, \
+  hipLaunchKernelGGL(k_trace_rays<FEAT>, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, D.dscene, D.pools[0].P, (uint32_t)seed, \
                      (uint32_t)(seed >> 32), (uint32_t)n, d_o.p, d_d.p, tm ? d_t.p : nullptr, d_out.p)
-    switch (scene_features(s->flat)) {
+    switch (extend_variant(scene_features(s->flat))) {
       case 0: CHIP_TRACE(0); break;
       case TF_QUADS: CHIP_TRACE(TF_QUADS); break;
       case TF_QUADS | TF_XFORM: CHIP_TRACE(TF_QUADS | TF_XFORM); break;
@@ -1143,7 +1415,7 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
     if ((e = hipDeviceSynchronize()) != hipSuccess) break;
     if ((e = hipMemcpy(out, d_out.p, n * sizeof(DHitOut), hipMemcpyDeviceToHost)) != hipSuccess) break;
     uint32_t err[4];
-    if ((e = hipMemcpy(err, s->p_err.p, sizeof(err), hipMemcpyDeviceToHost)) != hipSuccess) break;
+    if ((e = hipMemcpy(err, D.p_err.p, sizeof(err), hipMemcpyDeviceToHost)) != hipSuccess) break;
     if (err[0] & 1u) rc = fail("traversal stack overflow (scene nesting deeper than the device stack)");
   } while (0);
   d_o.release(); d_d.release(); d_t.release(); d_out.release();
@@ -1157,7 +1429,8 @@ int chip_camera_rays(chip_scene* s, uint64_t seed, size_t n, const uint32_t* xys
   if (n == 0) return 0;
   if (!xyss || !rays) return fail("null argument");
   if (n > 0xFFFFFFFFull) return fail("too many rays");
-  HIP_TRY(hipSetDevice(s->device));
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(s->dev.device));
   DevBuf<uint32_t> d_in;
   DevBuf<double> d_out;
   hipError_t e;
@@ -1165,7 +1438,7 @@ int chip_camera_rays(chip_scene* s, uint64_t seed, size_t n, const uint32_t* xys
     if ((e = d_in.alloc(4 * n)) != hipSuccess) break;
     if ((e = d_out.alloc(7 * n)) != hipSuccess) break;
     if ((e = hipMemcpy(d_in.p, xyss, 4 * n * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) break;
-    hipLaunchKernelGGL(k_camera_rays, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, s->dscene, (uint32_t)seed, (uint32_t)(seed >> 32),
+    hipLaunchKernelGGL(k_camera_rays, dim3(grid_for(n)), dim3(CHIP_BLOCK), 0, nullptr, s->dev.dscene, (uint32_t)seed, (uint32_t)(seed >> 32),
                        (uint32_t)n, d_in.p, d_out.p);
     if ((e = hipGetLastError()) != hipSuccess) break;
     if ((e = hipDeviceSynchronize()) != hipSuccess) break;

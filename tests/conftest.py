@@ -28,7 +28,7 @@ def oracle(pkg):
     src = [os.path.join(ROOT, "oracle", f) for f in ("oracle_capi.cpp", "caustic_oracle.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
-    return pkg.bindings.Backend(C.CDLL(so), "orc_", "oracle")
+    return pkg.bindings.Backend(C.CDLL(so), "orc_", "oracle", sum_dtype="float64")
 
 
 @pytest.fixture(scope="session")

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import fixed_ray_set  # noqa: E402
 
 pkg = importlib.import_module("rust-raytracer_amd")
-orc = pkg.bindings.Backend(C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_", "oracle")
+orc = pkg.bindings.Backend(C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_", "oracle", sum_dtype="float64")
 
 SCENES = ["random_spheres", "final", "cornell_box", "cornell_box_smoke", "three_spheres", "perlin_spheres", "lighted_cone_frustum", "scad_shapes"]
 KW = dict(width=32, spp=4, depth=8)

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = importlib.import_module("rust-raytracer_amd")
 import test_gpu_parity as T
 gpu = pkg.load_gpu()
-orc = pkg.bindings.Backend(C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_", "oracle")
+orc = pkg.bindings.Backend(C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_", "oracle", sum_dtype="float64")
 for variant in (0, 1, 2):
     sg, so = T._tie_scene(gpu, variant), T._tie_scene(orc, variant)
     o, d = T._tie_rays()
