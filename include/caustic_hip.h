@@ -214,6 +214,18 @@ int chip_resolve_device(chip_scene* s, const float* d_sum_rgb, size_t npixels, f
 int chip_resolve_device_flags(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, uint32_t flags,
                               void* stream);
 
+/* chip_render_accumulate_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  This entry point has no counterpart in the reference.  It calls no hipMalloc,
+ * hipFree, stream / event creation or other allocating routine: its path pool (32768 path slots with their counters,
+ * hit records, literal queue and traversal spill slabs, about 20 MB) is a static device array that every GPU the
+ * library runs on holds until the process ends, and the streams, events and pinned words it needs are made by
+ * chip_commit.  Limits, rejected with an error: the rectangle may hold at most chip_noalloc_max_pixels() = 32768 pixels
+ * (any number of strata; they are rendered batch after batch on `stream`), max_depth at most 254.
+ * CHIP_RENDER_TIME_KERNELS is ignored.  Same sums, bit for bit, as chip_render_accumulate_device.  All calls on one
+ * GPU share that GPU's array, from any scene: calls that overlap on one GPU race. */
+int chip_render_accumulate_noalloc(chip_scene* s, const chip_render_opts* opts, float* d_sum_rgb, void* stream, chip_stats* stats);
+uint32_t chip_noalloc_max_pixels(void);
+
 /* One frame over several GPUs of the machine, from one process: the shape of the reference's caller, which deals the
  * work of a frame to `num_cpus` threads and gathers their results (crates/cli/src/main.rs:119-186).
  * chip_commit_devices copies the committed scene to every device in `devices` (n entries, 1..64; an id may occur more

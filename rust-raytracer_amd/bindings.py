@@ -195,6 +195,8 @@ class Backend:
             "scene_from_flat": (C.c_int64, [p, C.POINTER(FlatScene), pi32]),
             "commit_devices": (i, [p, pi32, i]),
             "render_frame_multi": (i, [p, C.POINTER(RenderOpts), p, C.POINTER(C.c_uint8), C.POINTER(Stats)]),
+            "render_accumulate_noalloc": (i, [p, C.POINTER(RenderOpts), p, p, C.POINTER(Stats)]),
+            "noalloc_max_pixels": (C.c_uint32, []),
         }.items():
             if hasattr(self.lib, self.prefix + name):
                 f = self.fn(name)
@@ -480,6 +482,13 @@ class Scene:
         o = self._opts(seed, stratum_offset, stratum_stride, rect, strata_per_batch, flags)
         st = Stats()
         self._call("render_accumulate_device", C.byref(o), C.c_void_p(d_sum_ptr), C.c_void_p(stream), C.byref(st))
+        return st.as_dict()
+
+    def render_accumulate_noalloc(self, d_sum_ptr: int, seed=1, stratum_offset=0, stratum_stride=1, rect=None, strata_per_batch=0, flags=0, stream=0):
+        """`render_accumulate_device` through the entry point that allocates nothing (small rectangles only)."""
+        o = self._opts(seed, stratum_offset, stratum_stride, rect, strata_per_batch, flags)
+        st = Stats()
+        self._call("render_accumulate_noalloc", C.byref(o), C.c_void_p(d_sum_ptr), C.c_void_p(stream), C.byref(st))
         return st.as_dict()
 
     def commit_devices(self, devices):

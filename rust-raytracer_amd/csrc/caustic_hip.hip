@@ -1257,6 +1257,15 @@ int chip_render_accumulate_device(chip_scene* s, const chip_render_opts* opts, f
   return render_into(s, s->dev, opts, pl, d_sum_rgb, (hipStream_t)stream, stats, false);
 }
 
+int chip_render_accumulate_noalloc(chip_scene* s, const chip_render_opts* opts, float* d_sum_rgb, void* stream, chip_stats* stats) {
+  NEED_SCENE;
+  if (!opts || !d_sum_rgb) return fail("null argument");
+  RenderPlan pl;
+  if (plan_render(s, opts, pl)) return -1;
+  return render_into(s, s->dev, opts, pl, d_sum_rgb, (hipStream_t)stream, stats, true);
+}
+uint32_t chip_noalloc_max_pixels(void) { return CHIP_NOALLOC_PATHS; }
+
 int chip_resolve_device(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, void* stream) {
   return chip_resolve_device_flags(s, d_sum_rgb, npixels, d_out_gamma, d_out_rgb8, 0, stream);
 }
