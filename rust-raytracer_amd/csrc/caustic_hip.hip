@@ -135,7 +135,7 @@ struct DeviceState {
   int n_cus = 256;
   bool uploaded = false;
   DevBuf<DBvhNode> d_bvh;
-  DevBuf<DTNode> d_tnodes;
+  DevBuf<DWNode> d_wnodes;
   DevBuf<DSphere> d_spheres;
   DevBuf<DQuad> d_quads;
   DevBuf<DGroup> d_groups;
@@ -167,7 +167,7 @@ struct DeviceState {
   PathPool noalloc_pool{};
 
   void release_tables() {
-    d_bvh.release(); d_tnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release(); d_gbox.release();
+    d_bvh.release(); d_wnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release(); d_gbox.release();
     d_translates.release(); d_rotates.release(); d_scales.release(); d_discs.release(); d_cones.release(); d_media.release(); d_xchain.release(); d_materials.release();
     d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
     uploaded = false;
@@ -374,15 +374,17 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
   const char* e = getenv("CHIP_NO_LDS_CACHE");
   p.cache = !uncached && !s->flat.bvh.empty() && !(e && *e == '1');
   if (p.cache) {
-    p.block = (feat & TF_MEDIA_ANY) ? 512 : 1024;
+    p.block = (uint32_t)extend_block(feat, true);
     const bool ordered = true;  // an entry distance is kept beside every stack value
-    p.cd.stack_entries = ordered ? 6 : 12;
+    p.cd.stack_entries = ordered ? 8 : 12;
     if (const char* es = getenv("CHIP_LDS_STACK")) { int v = atoi(es); if (v >= 2 && v <= 16) p.cd.stack_entries = (uint32_t)v; }
-    uint32_t stack_bytes = p.cd.stack_entries * (ordered ? 8 : 4) * p.block;
-    uint32_t budget = (kLdsBytes - stack_bytes) / 64;
-    p.cd.n_bvh = (uint32_t)std::min<size_t>(s->flat.bvh.size(), budget);
-    p.cd.n_sph = (uint32_t)std::min<size_t>(s->flat.spheres.size(), budget - p.cd.n_bvh);
-    p.lds_bytes = 64 * (p.cd.n_bvh + p.cd.n_sph) + stack_bytes;
+    const uint32_t stack_bytes = p.cd.stack_entries * 8 * p.block;
+    const uint32_t node_bytes = 16 * CHIP_WNODE_U4, sphere_bytes = 64;
+    uint32_t budget = kLdsBytes - stack_bytes;
+    p.cd.n_bvh = (uint32_t)std::min<size_t>(s->flat.n_wide, budget / node_bytes);
+    budget -= p.cd.n_bvh * node_bytes;
+    p.cd.n_sph = (uint32_t)std::min<size_t>(s->flat.spheres.size(), budget / sphere_bytes);
+    p.lds_bytes = node_bytes * p.cd.n_bvh + sphere_bytes * p.cd.n_sph + stack_bytes;
   } else {
     p.block = CHIP_BLOCK;
     p.cd.stack_entries = CHIP_STACK_LDS;
@@ -431,13 +433,15 @@ static uint32_t extend_variant(uint32_t feat) {
 }
 // One bounce of traversal: the ordered traversal followed by a literal pass over the rays it handed back (normally none; all of
 // them in a reference_order render).
+// lit_expected: whether the literal queue is expected to hold rays (it sizes the literal pass's grid only: one block
+// drains a queue of any length, slowly).
 static int launch_extend(const chip_scene* s, const DeviceState& D, const PathPool& P, uint32_t feat, uint32_t n_live_upper, hipStream_t st,
-                         const BatchDesc& B, uint32_t bounce) {
+                         const BatchDesc& B, uint32_t bounce, bool lit_expected) {
   // the launch shape (threads per block, LDS split) must be planned for the instantiation that runs
   feat = extend_variant(feat);
   const ExtendPlan lit = plan_extend(s, feat, true);
   const ExtendPlan p = plan_extend(s, feat, false);
-  const uint32_t lit_upper = B.reference_order ? n_live_upper : std::min<uint32_t>(n_live_upper, 64u * CHIP_BLOCK);
+  const uint32_t lit_upper = B.reference_order ? n_live_upper : (lit_expected ? std::min<uint32_t>(n_live_upper, 64u * CHIP_BLOCK) : 1u);
 #define CHIP_EXT(FEAT)                                                                                   \
   {                                                                                                      \
     int rc_ = p.cache ? launch_extend_t<FEAT, true, true>(D, P, p, n_live_upper, st, B, bounce, 0)       \
@@ -551,6 +555,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
     bool traced = false;  // all bounces of the batch are enqueued; only the accumulation is still to come
     size_t batch = 0;
     uint32_t bounce = 0, live_upper = 0;
+    bool lit_expected = true;  // until a readback says the literal queue stayed empty
     // live-count readbacks in flight: the host runs ahead of the device and only learns a bounce's live
     // count (which sizes later grids and ends the batch early) when the copy has landed
     uint32_t rb_head = 0, rb_count = 0;
@@ -620,7 +625,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
       const uint32_t bounce = L.bounce;
       const uint32_t grid = std::min(grid_for(L.live_upper), shade_grid_max);
       if (time_kernels && stamp()) return -1;
-      if (launch_extend(s, D, P, feat, L.live_upper, L.st, B, bounce)) {
+      if (launch_extend(s, D, P, feat, L.live_upper, L.st, B, bounce, L.lit_expected)) {
         bag.failed = true;
         return -1;
       }
@@ -650,6 +655,8 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
       if (L.bounce < cam.max_depth && (bounce % 4) == 3) {
         const uint32_t j = (L.rb_head + L.rb_count) % 4;
         RENDER_TRY(hipMemcpyAsync(L.res->h_live + j, P.counters + (size_t)L.bounce * CHIP_CTR_STRIDE, sizeof(uint32_t), hipMemcpyDeviceToHost, L.st));
+        // ... and how many rays the bounce just enqueued handed to the literal pass (normally none)
+        RENDER_TRY(hipMemcpyAsync(L.res->h_live + 4 + j, P.counters + (size_t)bounce * CHIP_CTR_STRIDE + CHIP_CTR_LIT, sizeof(uint32_t), hipMemcpyDeviceToHost, L.st));
         RENDER_TRY(hipEventRecord(L.res->ev_rb[j], L.st));
         L.rb_count++;
         return 0;
@@ -670,6 +677,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
       }
       must = false;
       L.live_upper = std::min(L.live_upper, L.res->h_live[j]);
+      L.lit_expected = L.res->h_live[4 + j] != 0;
       L.rb_head = (L.rb_head + 1) % 4;
       L.rb_count--;
     }
@@ -685,6 +693,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
         L.batch = next_batch++;
         L.active = true;
         L.bounce = 0;
+        L.lit_expected = true;
         const Batch& bt = batches[L.batch];
         const PathPool& P = *L.P;
         n_paths_total += bt.B.n_paths;
@@ -761,7 +770,7 @@ static int upload_scene(chip_scene* s, DeviceState& D, const Flat& F) {
   }
   if (ensure_resources(D)) return -1;
   HIP_TRY(D.d_bvh.upload(F.bvh));
-  HIP_TRY(D.d_tnodes.upload(F.tnodes));
+  HIP_TRY(D.d_wnodes.upload(F.wnodes));
   HIP_TRY(D.d_spheres.upload(F.spheres));
   HIP_TRY(D.d_quads.upload(F.quads));
   HIP_TRY(D.d_groups.upload(F.groups));
@@ -780,7 +789,7 @@ static int upload_scene(chip_scene* s, DeviceState& D, const Flat& F) {
   HIP_TRY(D.d_texels.upload(s->host.texels));
   HIP_TRY(D.d_lights.upload(F.lights));
   DScene& T = D.dscene;
-  T.bvh = D.d_bvh.p; T.tnodes = D.d_tnodes.p; T.spheres = D.d_spheres.p; T.quads = D.d_quads.p; T.groups = D.d_groups.p; T.gchild = D.d_gchild.p; T.gbox = D.d_gbox.p;
+  T.bvh = D.d_bvh.p; T.wnodes = D.d_wnodes.p; T.spheres = D.d_spheres.p; T.quads = D.d_quads.p; T.groups = D.d_groups.p; T.gchild = D.d_gchild.p; T.gbox = D.d_gbox.p;
   T.translates = D.d_translates.p; T.rotates = D.d_rotates.p; T.scales = D.d_scales.p; T.discs = D.d_discs.p; T.cones = D.d_cones.p;
   T.media = D.d_media.p; T.xchain = D.d_xchain.p;
   T.materials = D.d_materials.p; T.textures = D.d_textures.p; T.perlins = D.d_perlins.p; T.texels = D.d_texels.p;

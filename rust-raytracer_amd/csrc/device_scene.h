@@ -43,18 +43,20 @@ struct alignas(64) DBvhNode {
   uint32_t pad[2];
 };
 
-// Traversal image of one BVH node: the boxes of its two children, rounded outward to f32, and the child
-// references (same index as the node's DBvhNode).  Used only for culling: a child is skipped when its
-// box cannot contain a hit closer than the current one, so these boxes only have to be conservative.
-// A BVH built from one node stores that node twice (bvh.rs:27-28); the duplicate gets an empty box.
-struct alignas(64) DTNode {
-  float lbox[6];  // left child: xmin,xmax,ymin,ymax,zmin,zmax
-  float rbox[6];  // right child
-  nref_t left, right;
-  uint32_t pad[2];
+// Culling node of the ordered traversal: up to four children with their boxes rounded outward to f32, one 128-byte
+// record (the granule HBM moves), planes stored component-wise so that the four slab tests of an axis read one
+// 16-byte word per plane.  Used only for culling: a child is skipped when its box cannot contain a hit closer than the
+// current one, so these boxes only have to be conservative.  The nodes of one BoundingVolumeHierarchy live in table
+// slots of that hierarchy's DBvhNodes, its root in the root's slot, so a reference to a hierarchy means the same
+// index in both tables.  Unused child slots hold NREF_NONE.
+struct alignas(128) DWNode {
+  float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];
+  nref_t child[4];
+  uint32_t pad[4];
 };
+#define CHIP_WNODE_U4 7  // 16-byte words of a DWNode the traversal reads
 
-struct alignas(16) DSphere {
+struct alignas(128) DSphere {
   double c[3];   // center at time 0
   double dc[3];  // center motion per unit time
   double r;
@@ -93,7 +95,7 @@ struct DGroup {
   uint32_t first, count;  // children are gchild[first .. first+count)
 };
 
-struct alignas(8) DTranslate {
+struct alignas(128) DTranslate {
   double off[3];
   nref_t child;
   nref_t parent_xform;             // innermost transform ancestor of this node, or NREF_NONE
@@ -102,7 +104,8 @@ struct alignas(8) DTranslate {
   // Where a traversal that enters this node continues: through a run of nested instances (each the other's only
   // content, e.g. Translate(Rotate(Box))) straight into the innermost one's space (enter_xform) and child.
   nref_t enter_xform, enter_child;
-  uint32_t pad;
+  uint32_t sphere_mat;  // with only_sphere: that sphere's mat word and, below, its geometry, so that testing the
+  double sc[3], sdc[3], sr;  // instance reads this one 128-byte record instead of two records one after the other
 };
 
 struct alignas(8) DRotate {
@@ -172,7 +175,7 @@ struct DCamera {  // Camera, camera.rs:202-231
 
 struct DScene {
   const DBvhNode* bvh;
-  const DTNode* tnodes;
+  const DWNode* wnodes;
   const DSphere* spheres;
   const DQuad* quads;
   const DGroup* groups;

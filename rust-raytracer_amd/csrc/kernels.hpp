@@ -224,7 +224,8 @@ extern __shared__ uint4 g_lds[];
 // compiler merges the "cached / not cached" branches into one generic-pointer load).
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) u32x4_t* lds_cv4_t;
-typedef __attribute__((address_space(3))) uint32_t* lds_u32_t;
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2_t* lds_u2_t;
 __device__ inline uint4 lds_read4(uint32_t i) {
   lds_cv4_t p = (lds_cv4_t)g_lds;
   u32x4_t t = p[i];
@@ -234,7 +235,7 @@ __device__ inline uint4 lds_read4(uint32_t i) {
 }
 
 struct TravStack {
-  lds_u32_t lds;  // this lane's column of the block's LDS stack
+  lds_u2_t lds;   // this lane's column of the block's LDS stack: (value, entry distance) per entry, one 8-byte word
   uint32_t* ovf;  // this thread's global spill slab
   int sp;
   uint32_t overflow;
@@ -242,10 +243,10 @@ struct TravStack {
   int lds_cap;      // entries kept in LDS
   uint32_t shift;   // log2 of the LDS words between consecutive entries of one lane (= threads per block)
 };
-// Read-only copy of the hottest scene records in LDS: the first n_bvh BVH nodes (the tables are in
-// breadth-first order, so these are the top of the tree) and the first n_sph spheres.  Each 64-byte
-// record is split into four 16-byte components stored in separate arrays (component k of record i at
-// [k * cap + i]), which spreads the lanes of a wave over the LDS banks.
+// Read-only copy of the hottest scene records in LDS: the first n_bvh culling nodes (the tables are in
+// breadth-first order, so these are the top of the tree) and the first n_sph spheres.  Each record is split
+// into its 16-byte components (seven of a culling node, four of a sphere) stored in separate arrays
+// (component k of record i at [k * cap + i]), which spreads the lanes of a wave over the LDS banks.
 struct NodeCache {
   uint32_t bvh_off, sph_off;  // first uint4 of the BVH / sphere component arrays in g_lds
   uint32_t n_bvh, n_sph;      // records cached
@@ -255,24 +256,25 @@ struct TravCounters {
   uint32_t bvh, prim;
 };
 
-// Entries are (value, entry distance) pairs in the ordered traversal (WITH_T): a deferred child is
-// dropped when it is popped if the closest hit found meanwhile is nearer than the child's box.
-// Markers and raw words are pushed with distance 0 and always survive.
+// Entries are (value, entry distance) pairs: in the ordered traversal (WITH_T) a deferred child is dropped
+// when it is popped if the closest hit found meanwhile is nearer than the child's box.  Markers and raw
+// words are pushed with distance 0 and always survive.
 template <bool WITH_T>
 __device__ inline void st_push(TravStack& s, uint32_t v, float t = 0.0f) {
   if (s.sp < s.lds_cap) {
-    s.lds[s.sp << s.shift] = v;
-    if (WITH_T) s.lds[(s.sp + s.lds_cap) << s.shift] = __float_as_uint(t);
+    u32x2_t e;
+    e.x = v; e.y = __float_as_uint(t);
+    s.lds[s.sp << s.shift] = e;
   } else if (s.sp < s.lds_cap + CHIP_STACK_OVF) {
-    if (WITH_T) { s.ovf[2 * (s.sp - s.lds_cap)] = v; s.ovf[2 * (s.sp - s.lds_cap) + 1] = __float_as_uint(t); }
-    else s.ovf[2 * (s.sp - s.lds_cap)] = v;  // same slots in both forms: a literal sub-traversal may run on an ordered stack
+    s.ovf[2 * (s.sp - s.lds_cap)] = v;
+    s.ovf[2 * (s.sp - s.lds_cap) + 1] = __float_as_uint(t);
   } else { s.overflow = 1; return; }
   s.sp++;
 }
 __device__ inline uint32_t st_pop_raw(TravStack& s, int base, bool with_t) {
   if (s.sp <= base) return NREF_NONE;
   s.sp--;
-  return s.sp < s.lds_cap ? s.lds[s.sp << s.shift] : s.ovf[2 * (s.sp - s.lds_cap)];
+  return s.sp < s.lds_cap ? s.lds[s.sp << s.shift].x : s.ovf[2 * (s.sp - s.lds_cap)];
 }
 template <bool WITH_T>
 __device__ inline uint32_t st_pop(TravStack& s, int base, float capf = 0.0f) {
@@ -282,13 +284,12 @@ __device__ inline uint32_t st_pop(TravStack& s, int base, float capf = 0.0f) {
     uint32_t v;
     float t = 0.0f;
     if (s.sp < s.lds_cap) {
-      v = s.lds[s.sp << s.shift];
-      if (WITH_T) t = __uint_as_float(s.lds[(s.sp + s.lds_cap) << s.shift]);
-    } else if (WITH_T) {
-      v = s.ovf[2 * (s.sp - s.lds_cap)];
-      t = __uint_as_float(s.ovf[2 * (s.sp - s.lds_cap) + 1]);
+      const u32x2_t e = s.lds[s.sp << s.shift];
+      v = e.x;
+      t = __uint_as_float(e.y);
     } else {
       v = s.ovf[2 * (s.sp - s.lds_cap)];
+      if (WITH_T) t = __uint_as_float(s.ovf[2 * (s.sp - s.lds_cap) + 1]);
     }
     if (!WITH_T || t <= capf) return v;
   }
@@ -306,14 +307,9 @@ struct SphereRec {
 __device__ inline double u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 template <bool CACHE>
 __device__ inline void load_bvh(const DScene& S, const NodeCache& C, uint32_t idx, BvhRec& n) {
-  uint4 a, b, c, d;
-  if (CACHE && idx < C.n_bvh) {
-    const uint32_t i = C.bvh_off + idx;
-    a = lds_read4(i); b = lds_read4(i + C.cap_bvh); c = lds_read4(i + 2 * C.cap_bvh); d = lds_read4(i + 3 * C.cap_bvh);
-  } else {
-    const uint4* p = reinterpret_cast<const uint4*>(S.bvh + idx);
-    a = p[0]; b = p[1]; c = p[2]; d = p[3];
-  }
+  // (the LDS cache holds culling nodes; the literal traversal reads the reference's nodes from memory)
+  const uint4* p = reinterpret_cast<const uint4*>(S.bvh + idx);
+  const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
   n.box[0] = u2d(a.x, a.y); n.box[1] = u2d(a.z, a.w);
   n.box[2] = u2d(b.x, b.y); n.box[3] = u2d(b.z, b.w);
   n.box[4] = u2d(c.x, c.y); n.box[5] = u2d(c.z, c.w);
@@ -336,24 +332,27 @@ __device__ inline void load_sphere(const DScene& S, const NodeCache& C, uint32_t
   n.mat = d.z;
 }
 
-struct TNodeRec {
-  float l[6], r[6];
-  nref_t left, right;
+struct WNodeRec {
+  float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];
+  nref_t child[4];
 };
+__device__ inline void u4_to_f4(const uint4& u, float* f) {
+  f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+}
 template <bool CACHE>
-__device__ inline void load_tnode(const DScene& S, const NodeCache& C, uint32_t idx, TNodeRec& n) {
-  uint4 a, b, c, d;
+__device__ inline void load_wnode(const DScene& S, const NodeCache& C, uint32_t idx, WNodeRec& n) {
+  uint4 q[CHIP_WNODE_U4];
   if (CACHE && idx < C.n_bvh) {
     const uint32_t i = C.bvh_off + idx;
-    a = lds_read4(i); b = lds_read4(i + C.cap_bvh); c = lds_read4(i + 2 * C.cap_bvh); d = lds_read4(i + 3 * C.cap_bvh);
+#pragma unroll
+    for (int k = 0; k < CHIP_WNODE_U4; k++) q[k] = lds_read4(i + k * C.cap_bvh);
   } else {
-    const uint4* p = reinterpret_cast<const uint4*>(S.tnodes + idx);
-    a = p[0]; b = p[1]; c = p[2]; d = p[3];
+    const uint4* p = reinterpret_cast<const uint4*>(S.wnodes + idx);
+#pragma unroll
+    for (int k = 0; k < CHIP_WNODE_U4; k++) q[k] = p[k];
   }
-  n.l[0] = __uint_as_float(a.x); n.l[1] = __uint_as_float(a.y); n.l[2] = __uint_as_float(a.z); n.l[3] = __uint_as_float(a.w);
-  n.l[4] = __uint_as_float(b.x); n.l[5] = __uint_as_float(b.y); n.r[0] = __uint_as_float(b.z); n.r[1] = __uint_as_float(b.w);
-  n.r[2] = __uint_as_float(c.x); n.r[3] = __uint_as_float(c.y); n.r[4] = __uint_as_float(c.z); n.r[5] = __uint_as_float(c.w);
-  n.left = d.x; n.right = d.y;
+  u4_to_f4(q[0], n.lo_x); u4_to_f4(q[1], n.hi_x); u4_to_f4(q[2], n.lo_y); u4_to_f4(q[3], n.hi_y); u4_to_f4(q[4], n.lo_z); u4_to_f4(q[5], n.hi_z);
+  n.child[0] = q[6].x; n.child[1] = q[6].y; n.child[2] = q[6].z; n.child[3] = q[6].w;
 }
 
 // Conservative f32 slab test of one child box against the ray's culling form: [entry, exit] contains
@@ -670,28 +669,44 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
   for (;;) {
     // BVH descent (bvh.rs:58-76): test the node's own box over (tmin, best_t); left first, right deferred.
     if (ORD) {
-      // both child boxes are tested here; the nearer child is visited first, the other one deferred
+      // the boxes of up to four children are tested here; the nearest child is visited next, the others are deferred
+      // nearest on top.  A child's sort key is its entry distance (positive, so its bits order like the value) with
+      // the two lowest bits replaced by the child's slot; the distance a deferred child carries is thereby rounded
+      // down, which keeps the pop-time test conservative.
       while (NREF_KIND(node) == NK_BVH) {
-        TNodeRec n;
-        load_tnode<CACHE>(S, C, NREF_INDEX(node), n);
+        WNodeRec n;
+        load_wnode<CACHE>(S, C, NREF_INDEX(node), n);
 #if CHIP_TRAV_PROFILE  /* counts wave-level loop trips instead of per-lane visits */
         if (__lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) cnt.bvh++;
 #else
         cnt.bvh++;
 #endif
-        float el, xl, er, xr;
-        cull_slab(n.l, r, el, xl);
-        cull_slab(n.r, r, er, xr);
-        const bool hl = el <= xl, hr = er <= xr;
-        if (hl && hr) {
-          const bool swap = er < el;
-          st_push<true>(st, swap ? n.left : n.right, swap ? el : er);
-          node = swap ? n.right : n.left;
-        } else if (hl || hr) {
-          node = hl ? n.left : n.right;
-        } else {
-          node = st_pop<true>(st, base, r.capf);
+        uint32_t key[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float x0 = fmaf(n.lo_x[k], r.m_lo[0], r.c_lo[0]), x1 = fmaf(n.hi_x[k], r.m_hi[0], r.c_hi[0]);
+          const float y0 = fmaf(n.lo_y[k], r.m_lo[1], r.c_lo[1]), y1 = fmaf(n.hi_y[k], r.m_hi[1], r.c_hi[1]);
+          const float z0 = fmaf(n.lo_z[k], r.m_lo[2], r.c_lo[2]), z1 = fmaf(n.hi_z[k], r.m_hi[2], r.c_hi[2]);
+          const float en = fmaxf(fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1)), CHIP_CULL_TMIN);
+          const float ex = fminf(fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)), r.capf);
+          key[k] = (en <= ex && n.child[k] != NREF_NONE) ? ((__float_as_uint(en) & ~3u) | (uint32_t)k) : 0xFFFFFFFFu;
         }
+        // sorting network on four keys
+#define CHIP_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
+        CHIP_CSWAP(0, 1) CHIP_CSWAP(2, 3) CHIP_CSWAP(0, 2) CHIP_CSWAP(1, 3) CHIP_CSWAP(1, 2)
+#undef CHIP_CSWAP
+#define CHIP_CHILD(kk) (((kk) & 2u) ? (((kk) & 1u) ? n.child[3] : n.child[2]) : (((kk) & 1u) ? n.child[1] : n.child[0]))
+        if (key[0] == 0xFFFFFFFFu) {
+          node = st_pop<true>(st, base, r.capf);
+        } else {
+          if (__any(key[2] != 0xFFFFFFFFu)) {  // three or four children in reach: rare enough to be worth the branch
+            if (key[3] != 0xFFFFFFFFu) st_push<true>(st, CHIP_CHILD(key[3]), __uint_as_float(key[3] & ~3u));
+            if (key[2] != 0xFFFFFFFFu) st_push<true>(st, CHIP_CHILD(key[2]), __uint_as_float(key[2] & ~3u));
+          }
+          if (key[1] != 0xFFFFFFFFu) st_push<true>(st, CHIP_CHILD(key[1]), __uint_as_float(key[1] & ~3u));
+          node = CHIP_CHILD(key[0]);
+        }
+#undef CHIP_CHILD
       }
     } else {
       while (NREF_KIND(node) == NK_BVH) {
@@ -794,14 +809,18 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       if (t.only_sphere != NREF_NONE) {
         // A Translate around a single sphere (translate.rs:26-38 over group.rs:44-54 over sphere.rs:99-121): the same
         // arithmetic on the offset origin, without entering and leaving the instance on the stack.
+        // The sphere's geometry rides in the Translate's own record (one 128-byte fetch instead of two dependent ones).
         const V3 outer_o = r.o;
         r.o = r.o - ld3(t.off);
         const nref_t c = t.only_sphere;
+        SphereRec sp;
+        sp.c[0] = t.sc[0]; sp.c[1] = t.sc[1]; sp.c[2] = t.sc[2];
+        sp.dc[0] = t.sdc[0]; sp.dc[1] = t.sdc[1]; sp.dc[2] = t.sdc[2];
+        sp.r = t.sr;
+        sp.mat = t.sphere_mat;
         double tt;
         cnt.prim++;
-        if (ORD ? sphere_hit_incl(S.spheres[NREF_INDEX(c)], r, tmin, best_t, tt) : sphere_hit(S.spheres[NREF_INDEX(c)], r, tmin, best_t, tt)) {
-          CHIP_TAKE(c, tt, S.spheres[NREF_INDEX(c)].mat)
-        }
+        if (ORD ? sphere_hit_incl(sp, r, tmin, best_t, tt) : sphere_hit(sp, r, tmin, best_t, tt)) { CHIP_TAKE(c, tt, sp.mat) }
         r.o = outer_o;
       } else {
         st_push<ORD>(st, NREF(NK_EXIT_TRANSLATE, idx));
@@ -1472,30 +1491,39 @@ struct CacheDesc {
   uint32_t stack_entries;    // per-lane stack entries kept in LDS
 };
 // Threads per block of the traversal kernel: with the LDS scene cache one block owns a whole CU's LDS.
-__host__ __device__ constexpr int extend_block(uint32_t F, bool CACHE) { return CACHE ? ((F & TF_MEDIA_ANY) ? 512 : 1024) : CHIP_BLOCK; }
+#ifndef CHIP_EXT_BLOCK_QUADS
+#define CHIP_EXT_BLOCK_QUADS 1024  // block of the cached kernel for scenes with more than bare spheres
+#endif
+__host__ __device__ constexpr int extend_block(uint32_t F, bool CACHE) {
+  return CACHE ? ((F & TF_MEDIA_ANY) ? 512 : (F == 0 ? 1024 : CHIP_EXT_BLOCK_QUADS)) : CHIP_BLOCK;
+}
 // Waves per SIMD the traversal kernel is register-allocated for.  The LDS-cached sphere-scene kernel asks for 6
 // (at most 80 VGPRs) although only 4 of its own waves fit beside its LDS: the registers it leaves free are
 // what lets two shade waves per SIMD of the other batch run next to it.
+#ifndef CHIP_EXT0_WAVES
+#define CHIP_EXT0_WAVES 5
+#endif
 __host__ __device__ constexpr int extend_min_waves(uint32_t F, bool CACHE) {
-  return CACHE ? (F == 0 ? 6 : 1) : ((F & TF_MEDIA) ? 1 : ((F & TF_XFORM) ? 2 : CHIP_EXTEND_WAVES));
+  return CACHE ? (F == 0 ? CHIP_EXT0_WAVES : 1) : ((F & TF_MEDIA) ? 1 : ((F & TF_XFORM) ? 2 : CHIP_EXTEND_WAVES));
 }
 // B0: the instantiation for bounce 0 (camera rays are computed, not loaded), kept apart so that the
 // camera code does not cost the other bounces registers.
 template <uint32_t F, bool CACHE, bool ORD, bool B0>
 __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CACHE)) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg, CacheDesc cd, uint32_t lit_pass) {
   const uint32_t bounce = B0 ? 0u : bounce_arg;
-  // LDS layout: [4 x n_bvh uint4][4 x n_sph uint4][stack_entries x blockDim u32 values][the same again: entry distances (ORD)]
-  const NodeCache C{0u, 4u * cd.n_bvh, cd.n_bvh, cd.n_sph, cd.n_bvh, cd.n_sph};
-  uint32_t* lds_stack = reinterpret_cast<uint32_t*>(g_lds) + 16u * (cd.n_bvh + cd.n_sph);
+  // LDS layout: [7 x n_bvh uint4: culling nodes][4 x n_sph uint4: spheres][stack_entries x blockDim (value, distance) pairs]
+  const NodeCache C{0u, (uint32_t)CHIP_WNODE_U4 * cd.n_bvh, cd.n_bvh, cd.n_sph, cd.n_bvh, cd.n_sph};
+  uint2* lds_stack = reinterpret_cast<uint2*>(g_lds + (CHIP_WNODE_U4 * cd.n_bvh + 4u * cd.n_sph));
   uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
   const uint32_t n_live = lit_pass ? ctr[CHIP_CTR_LIT] : ctr[0];
   if ((size_t)blockIdx.x * 64u >= n_live) return;  // the grid is sized from an upper bound: surplus blocks leave at once
   if (CACHE) {
     for (uint32_t i = threadIdx.x; i < cd.n_bvh; i += blockDim.x) {
-      const uint4* p = ORD ? reinterpret_cast<const uint4*>(S.tnodes + i) : reinterpret_cast<const uint4*>(S.bvh + i);
-      g_lds[i] = p[0]; g_lds[cd.n_bvh + i] = p[1]; g_lds[2 * cd.n_bvh + i] = p[2]; g_lds[3 * cd.n_bvh + i] = p[3];
+      const uint4* p = reinterpret_cast<const uint4*>(S.wnodes + i);
+#pragma unroll
+      for (int k = 0; k < CHIP_WNODE_U4; k++) g_lds[k * cd.n_bvh + i] = p[k];
     }
-    const uint32_t so = 4u * cd.n_bvh;
+    const uint32_t so = (uint32_t)CHIP_WNODE_U4 * cd.n_bvh;
     for (uint32_t i = threadIdx.x; i < cd.n_sph; i += blockDim.x) {
       const uint4* p = reinterpret_cast<const uint4*>(S.spheres + i);
       g_lds[so + i] = p[0]; g_lds[so + cd.n_sph + i] = p[1]; g_lds[so + 2 * cd.n_sph + i] = p[2]; g_lds[so + 3 * cd.n_sph + i] = p[3];
@@ -1507,7 +1535,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = __lane_id();
   TravStack st;
-  st.lds = (lds_u32_t)lds_stack + threadIdx.x;
+  st.lds = (lds_u2_t)lds_stack + threadIdx.x;
   st.ovf = P.ovf + (size_t)gtid * (2 * CHIP_STACK_OVF);
   st.overflow = 0;
   st.redo = 0;
@@ -1939,10 +1967,10 @@ struct DHitOut {
 template <uint32_t F>
 __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P, uint32_t seed_lo, uint32_t seed_hi, uint32_t n,
                                                            const double* o, const double* d, const double* tm, DHitOut* out) {
-  __shared__ uint32_t lds_stack[2 * CHIP_STACK_LDS * CHIP_BLOCK];
+  __shared__ uint2 lds_stack[CHIP_STACK_LDS * CHIP_BLOCK];
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   TravStack st;
-  st.lds = (lds_u32_t)lds_stack + threadIdx.x;
+  st.lds = (lds_u2_t)lds_stack + threadIdx.x;
   st.ovf = P.ovf + (size_t)gtid * (2 * CHIP_STACK_OVF);
   st.overflow = 0;
   st.redo = 0;

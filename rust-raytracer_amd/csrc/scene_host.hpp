@@ -85,7 +85,7 @@ struct HNode {
 
 struct Flat {
   std::vector<DBvhNode> bvh;
-  std::vector<DTNode> tnodes;          // culling image of bvh[], same indices
+  std::vector<DWNode> wnodes;          // 4-wide culling nodes of the ordered traversal, in slots of bvh[] (same indices for hierarchy roots)
   std::vector<Box6> bvh_child_box[2];  // boxes of each BVH node's left / right child (flattening scratch)
   std::vector<uint8_t> bvh_is_root;    // node was the top of a BoundingVolumeHierarchy::new call (flattening scratch)
   std::vector<DSphere> spheres;
@@ -104,6 +104,7 @@ struct Flat {
   nref_t root = NREF_NONE;
   uint32_t has_lights = 0, lights_is_group = 0;
   uint32_t loose_geometry = 0;  // some primitive of the world is not bounded by its own box
+  uint32_t n_wide = 0;          // culling nodes in use: wnodes[0 .. n_wide)
 };
 
 struct HostScene {
@@ -586,7 +587,13 @@ struct HostScene {
             else if (NREF_KIND(c) == NK_GROUP && F.groups[NREF_INDEX(c)].count == 1 && NREF_KIND(F.gchild[F.groups[NREF_INDEX(c)].first]) == NK_SPHERE)
               only = F.gchild[F.groups[NREF_INDEX(c)].first];
             F.translates[idx].only_sphere = only;
-            F.translates[idx].pad = 0;
+            if (only != NREF_NONE) {
+              const DSphere& sp = F.spheres[NREF_INDEX(only)];
+              DTranslate& t = F.translates[idx];
+              t.sphere_mat = sp.mat;
+              for (int i = 0; i < 3; i++) { t.sc[i] = sp.c[i]; t.sdc[i] = sp.dc[i]; }
+              t.sr = sp.r;
+            }
           }
           else if (n.kind == CHIP_NODE_ROTATE) F.rotates[idx].child = c;
           else F.scales[idx].child = c;
@@ -658,7 +665,7 @@ struct HostScene {
       }
     }
     reorder_bvh_breadth_first(F);
-    build_tnodes(F);
+    build_wnodes(F);
     if (F.bvh.size() >= (1u << 28) || F.spheres.size() >= (1u << 28) || F.quads.size() >= (1u << 28) || F.discs.size() >= (1u << 28) || F.cones.size() >= (1u << 28))
       throw std::runtime_error("scene too large for 28-bit node indices");
   }
@@ -689,22 +696,41 @@ struct HostScene {
     };
     if (NREF_KIND(F.root) == NK_BVH) bfs_from(NREF_INDEX(F.root));
     for (uint32_t i = 0; i < n; i++) bfs_from(i);  // BVHs below groups / transforms / media, in table order
+    apply_bvh_order(F, order);
+  }
+  // Renumbers the hierarchy tables: entry i of the new tables is entry order[i] of the old ones; every reference
+  // to a hierarchy node follows.
+  static void apply_bvh_order(Flat& F, const std::vector<uint32_t>& order) {
+    const size_t n = F.bvh.size();
+    std::vector<uint32_t> newidx(n, 0);
+    for (size_t i = 0; i < n; i++) newidx[order[i]] = (uint32_t)i;
     auto remap = [&](nref_t r) -> nref_t { return NREF_KIND(r) == NK_BVH ? NREF(NK_BVH, newidx[NREF_INDEX(r)]) : r; };
     std::vector<DBvhNode> nb(n);
-    std::vector<Box6> cb[2] = {std::vector<Box6>(n), std::vector<Box6>(n)};
-    std::vector<uint8_t> ir(n);
     for (size_t i = 0; i < n; i++) {
-      ir[i] = F.bvh_is_root[order[i]];
       nb[i] = F.bvh[order[i]];
       nb[i].left = remap(nb[i].left);
       nb[i].right = remap(nb[i].right);
-      cb[0][i] = F.bvh_child_box[0][order[i]];
-      cb[1][i] = F.bvh_child_box[1][order[i]];
     }
     F.bvh.swap(nb);
-    F.bvh_child_box[0].swap(cb[0]);
-    F.bvh_child_box[1].swap(cb[1]);
-    F.bvh_is_root.swap(ir);
+    if (F.wnodes.size() == n) {
+      std::vector<DWNode> nw(n);
+      for (size_t i = 0; i < n; i++) {
+        nw[i] = F.wnodes[order[i]];
+        for (int k = 0; k < 4; k++) nw[i].child[k] = remap(nw[i].child[k]);
+      }
+      F.wnodes.swap(nw);
+    }
+    for (int side = 0; side < 2; side++)
+      if (F.bvh_child_box[side].size() == n) {
+        std::vector<Box6> cb(n);
+        for (size_t i = 0; i < n; i++) cb[i] = F.bvh_child_box[side][order[i]];
+        F.bvh_child_box[side].swap(cb);
+      }
+    if (F.bvh_is_root.size() == n) {
+      std::vector<uint8_t> ir(n);
+      for (size_t i = 0; i < n; i++) ir[i] = F.bvh_is_root[order[i]];
+      F.bvh_is_root.swap(ir);
+    }
     F.root = remap(F.root);
     for (nref_t& c : F.gchild) c = remap(c);
     for (DTranslate& t : F.translates) { t.child = remap(t.child); t.enter_child = remap(t.enter_child); }
@@ -818,20 +844,33 @@ struct HostScene {
     size_t m = (size_t)(mid - leaves.begin());
     return (m == lo || m == hi) ? lo + n / 2 : m;
   }
-  static void build_tnodes(Flat& F) {
+  static void set_wide_child(DWNode& w, int k, nref_t ref, const float* b) {
+    w.child[k] = ref;
+    w.lo_x[k] = b[0]; w.hi_x[k] = b[1]; w.lo_y[k] = b[2]; w.hi_y[k] = b[3]; w.lo_z[k] = b[4]; w.hi_z[k] = b[5];
+  }
+  // Binary SAH tree over one hierarchy's members, then folded into nodes of up to four children: a node takes the two
+  // children of its binary node and, while it has room, replaces the inner child with the largest box by that
+  // child's own two children.
+  struct BinNode {
+    Box6 box;
+    int left = -1, right = -1;  // -1: a leaf holding `ref`
+    nref_t ref = NREF_NONE;
+  };
+  static void build_wnodes(Flat& F) {
     const size_t n = F.bvh.size();
-    F.tnodes.resize(n);
+    F.wnodes.resize(n);
     for (size_t i = 0; i < n; i++) {
-      DTNode& t = F.tnodes[i];
-      std::memset(&t, 0, sizeof(t));
-      t.left = t.right = NREF_NONE;
-      set_empty_box(t.lbox);
-      set_empty_box(t.rbox);
+      DWNode& w = F.wnodes[i];
+      std::memset(&w, 0, sizeof(w));
+      for (int k = 0; k < 4; k++) w.child[k] = NREF_NONE;
     }
     std::vector<SahLeaf> leaves;
     std::vector<uint32_t> slots, stack;
-    struct Job { size_t lo, hi; uint32_t slot; };
-    std::vector<Job> queue;
+    std::vector<BinNode> bin;
+    struct Job { size_t lo, hi; int node; };
+    std::vector<Job> jobs;
+    struct WJob { int bin; uint32_t slot; };
+    std::vector<WJob> queue;
     for (size_t root = 0; root < n; root++) {
       if (!F.bvh_is_root[root]) continue;
       // members and table slots of this hierarchy: walk its reference nodes
@@ -857,50 +896,100 @@ struct HostScene {
       std::sort(slots.begin(), slots.end());
       // drop members with an empty box (the two empty Groups of an empty hierarchy, bvh.rs:23-26)
       leaves.erase(std::remove_if(leaves.begin(), leaves.end(), [](const SahLeaf& l) { return !(l.box.v[0] <= l.box.v[1]); }), leaves.end());
+      DWNode& wroot = F.wnodes[root];
       if (leaves.empty()) {
-        // an empty hierarchy: its reference children (two empty Groups) stand in, behind boxes every ray hits;
-        // visiting them does nothing, whereas an absent child would read as the end of the traversal
-        F.tnodes[root].left = F.bvh[root].left;
-        F.tnodes[root].right = F.bvh[root].right;
+        // an empty hierarchy: its reference children (two empty Groups) stand in, behind boxes every ray hits (the
+        // slab test orders each axis's two plane distances with min / max, so an inverted box is hit by every ray);
+        // visiting them does nothing, whereas a node without children would read as the end of the traversal
+        float e[6];
+        set_empty_box(e);
+        set_wide_child(wroot, 0, F.bvh[root].left, e);
+        set_wide_child(wroot, 1, F.bvh[root].right, e);
         continue;
       }
       if (leaves.size() == 1) {
-        // Both children are the member, as in the reference (bvh.rs:27-28).  An absent child cannot be expressed
-        // by an inverted box: the slab test orders each axis's two plane distances with min / max, so an
-        // inverted box is one that every ray hits.
-        DTNode& t = F.tnodes[root];
-        t.left = t.right = leaves[0].ref;
-        set_cull_box(t.lbox, leaves[0].box);
-        set_cull_box(t.rbox, leaves[0].box);
+        // the reference holds a single member as both children and visits it twice (bvh.rs:27-28); the second visit
+        // finds what the first one found (a ConstantMedium's two samples are taken in its one visit, DMedium::tests)
+        float b[6];
+        set_cull_box(b, leaves[0].box);
+        set_wide_child(wroot, 0, leaves[0].ref, b);
         continue;
       }
-      // breadth-first construction; node k of this hierarchy takes the k-th smallest slot
+      // binary tree, explicit work list (a chain of uneven splits can be as deep as it is long)
+      bin.clear();
+      bin.push_back(BinNode{});
+      jobs.clear();
+      jobs.push_back(Job{0, leaves.size(), 0});
+      while (!jobs.empty()) {
+        const Job job = jobs.back();
+        jobs.pop_back();
+        Box6 bb = leaves[job.lo].box;
+        for (size_t i = job.lo + 1; i < job.hi; i++) bb = box_merge(bb, leaves[i].box);
+        bin[job.node].box = bb;
+        if (job.hi - job.lo == 1) {
+          bin[job.node].ref = leaves[job.lo].ref;
+          continue;
+        }
+        const size_t mid = sah_split(leaves, job.lo, job.hi);
+        const int l = (int)bin.size(), r = l + 1;
+        bin.push_back(BinNode{});
+        bin.push_back(BinNode{});
+        bin[job.node].left = l;
+        bin[job.node].right = r;
+        jobs.push_back(Job{job.lo, mid, l});
+        jobs.push_back(Job{mid, job.hi, r});
+      }
+      // breadth-first fold; wide node k of this hierarchy takes the k-th smallest slot (top levels first)
       queue.clear();
-      queue.push_back(Job{0, leaves.size(), slots[0]});
+      queue.push_back(WJob{0, slots[0]});
       size_t next_slot = 1;
       for (size_t q = 0; q < queue.size(); q++) {
-        const Job job = queue[q];
-        const size_t mid = sah_split(leaves, job.lo, job.hi);
-        DTNode& t = F.tnodes[job.slot];
-        for (int side = 0; side < 2; side++) {
-          const size_t lo = side == 0 ? job.lo : mid, hi = side == 0 ? mid : job.hi;
-          Box6 bb = leaves[lo].box;
-          for (size_t i = lo + 1; i < hi; i++) bb = box_merge(bb, leaves[i].box);
+        const WJob job = queue[q];
+        int kids[4] = {bin[job.bin].left, bin[job.bin].right, -1, -1};
+        int nk = 2;
+        while (nk < 4) {
+          int best = -1;
+          double best_area = -1.0;
+          for (int k = 0; k < nk; k++)
+            if (bin[kids[k]].left >= 0) {
+              const double a = box_area(bin[kids[k]].box);
+              if (a > best_area) { best_area = a; best = k; }
+            }
+          if (best < 0) break;
+          const int open = kids[best];
+          kids[best] = bin[open].left;
+          kids[nk++] = bin[open].right;
+        }
+        DWNode& w = F.wnodes[job.slot];
+        for (int k = 0; k < nk; k++) {
+          const BinNode& c = bin[kids[k]];
           nref_t ref;
-          if (hi - lo == 1) {
-            ref = leaves[lo].ref;
+          if (c.left < 0) {
+            ref = c.ref;
           } else {
             const uint32_t slot = slots[next_slot++];
             ref = NREF(NK_BVH, slot);
-            queue.push_back(Job{lo, hi, slot});
+            queue.push_back(WJob{kids[k], slot});
           }
-          if (side == 0) { t.left = ref; set_cull_box(t.lbox, bb); }
-          else { t.right = ref; set_cull_box(t.rbox, bb); }
+          float b[6];
+          set_cull_box(b, c.box);
+          set_wide_child(w, k, ref, b);
         }
       }
     }
     for (int k = 0; k < 2; k++) { F.bvh_child_box[k].clear(); F.bvh_child_box[k].shrink_to_fit(); }
     F.bvh_is_root.clear();
+    // The slots that hold culling nodes move to the front of the tables (hierarchy roots keep one index in both
+    // tables because both are renumbered alike), top levels first, so that the leading records are the hottest
+    // ones: those are what the traversal kernel copies into LDS.
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    for (size_t i = 0; i < n; i++)
+      if (F.wnodes[i].child[0] != NREF_NONE) order.push_back((uint32_t)i);
+    F.n_wide = (uint32_t)order.size();
+    for (size_t i = 0; i < n; i++)
+      if (F.wnodes[i].child[0] == NREF_NONE) order.push_back((uint32_t)i);
+    apply_bvh_order(F, order);
   }
 
   // Preorder dump in the order the reference's tree would be walked.
