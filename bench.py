@@ -4,13 +4,24 @@
 A step is one full frame: every (pixel, stratum) path sample of the 1920x1080, 1024 spp, depth 50
 RTIOW final random-spheres scene.  With N GPUs (one process per GPU, launched by torch.distributed.run)
 the strata are dealt round-robin over the ranks, every rank renders its share into an f32 radiance
-sum on its GPU, one RCCL reduce gathers the sums on rank 0, which resolves the image.  The scene is
-committed (flattened and uploaded) before the timed region, so inputs are resident in HBM.
+sum on its GPU, one RCCL reduce gathers the sums on rank 0, which resolves the image
+(`rust-raytracer_amd/distributed.py: frame_step`).  The scene is committed (flattened and uploaded) before
+the timed region, so inputs are resident in HBM.
 
-Prints ONE JSON line on rank 0 (metric = whole-job path-samples/s).
+Prints ONE JSON line on rank 0 (metric = whole-job path-samples/s).  Besides the contract's fields:
+  roofline      the dominant kernel (closest-hit traversal) against the resource that bounds it on this workload,
+                vector-ALU issue: lane-operations per second.  The work per ray segment comes from a committed
+                rocprofv3 PMC summary (profiles/r02/roofline_profile.json, with the git hash it was taken at and the
+                hash of the kernel source it describes); the segments and the launch durations are measured live.
+  roofline_s5   the same kernel on the one configuration whose scene tables do not fit the caches (the 100^3
+                OpenSCAD-shaped instance lattice), against HBM bandwidth: algorithmic node / instance bytes per
+                launch over the live launch duration, with the PMC-measured traffic beside it.
+  rank_share    one rank's share of an 8-GPU job timed on this GPU (every 8th stratum, no reduce).
+  cpu_baseline  the CPU oracle timed on a bounded sample of the same workload (N = 1 only).
 """
 import argparse
 import ctypes as C
+import hashlib
 import importlib
 import json
 import os
@@ -25,14 +36,36 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("rust-raytracer_amd")
 
 # Device record sizes that define the algorithmic bytes of one ray segment of the traversal kernel.
-BYTES_BVH_NODE = 64    # DTNode: f32 boxes of both children (2 x 6 f32) + two child refs, one 64-B record per visit
-BYTES_SPHERE = 64      # the part of DSphere a test reads: centre, motion, radius (7 f64) + material word
-BYTES_SEGMENT_STATE = 64 + 16  # PathRay record read (it carries the path id; not at bounce 0, whose rays are computed), PathHit record write
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-# HBM bytes per launch of the traversal kernel on the default workload (1920x1080, 64-strata batches, depth 50),
-# from rocprofv3 PMC passes of this build (2 x FETCH_SIZE + WRITE_SIZE, in KB, summed over the launches of one
-# frame and divided by their number): profiles/r01/pmc_traffic_k_extend.json.  None for any other workload.
-PMC_TRAFFIC_DEFAULT_WORKLOAD = 414.0e6
+BYTES_WIDE_NODE = 112   # DWNode: f32 boxes of four children (6 x 16 B) + four child references (16 B) of a 128-B record
+BYTES_SPHERE = 64       # the part of a sphere record a test reads: centre, motion, radius (7 f64) + material word
+BYTES_INSTANCE = 128    # DTranslate with its sphere inlined: one record per instanced-sphere test
+BYTES_SEGMENT_STATE = 64 + 16  # PathRay record read (not at bounce 0, whose rays are computed), PathHit record written
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+# Vector-ALU issue peak: a SIMD issues one plain wave64 instruction per 4 cycles (16 lanes per clock; the 157 TFLOP/s
+# fp32 figure of the data sheet is this rate times 2 for packed f32 times 2 for multiply-add):
+# 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r02", "roofline_profile.json")
+KERNEL_SOURCES = [os.path.join(ROOT, "rust-raytracer_amd", "csrc", f) for f in ("kernels.hpp", "device_scene.h")]
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_profile():
+    """The committed PMC-derived figures; None (and the reason) when absent or taken on other kernel sources."""
+    if not os.path.exists(PROFILE_JSON):
+        return None, "no profile file"
+    with open(PROFILE_JSON) as fh:
+        prof = json.load(fh)
+    if prof.get("kernel_source_sha256_16") != kernel_source_hash():
+        return prof, "profile was taken on other kernel sources (stale)"
+    return prof, None
 
 
 def cpu_baseline(width, depth, seed):
@@ -48,9 +81,7 @@ def cpu_baseline(width, depth, seed):
     spp = 64
     so = pkg.scenes.build(orc, "random_spheres", width=width, spp=spp, depth=depth)
     t0 = time.perf_counter()
-    import numpy as np
-
-    _, _, st = so.render_frame(seed=seed, sum_dtype=np.float64, flags=(threads << 8))
+    _, _, st = so.render_frame(seed=seed, flags=(threads << 8))
     dt = time.perf_counter() - t0
     return {
         "value": st["paths"] / dt,
@@ -59,6 +90,65 @@ def cpu_baseline(width, depth, seed):
         "kind": "port",
         "sample": f"same scene, {so.image_size()[0]}x{so.image_size()[1]}, {spp} spp (8x8 strata), depth {depth}: {st['paths']} path-samples in {dt:.1f} s",
     }
+
+
+def traversal_sums(stats):
+    seg = sum(s["segments"] for s in stats)
+    return {
+        "seg": seg,
+        "bvh": sum(s["bvh_visits"] for s in stats),
+        "prim": sum(s["prim_tests"] for s in stats),
+        "launches": sum(s["trace_launches"] for s in stats),
+        "ms_trace": sum(s["ms_trace"] for s in stats),
+        "ms_total": sum(s["ms_total"] for s in stats),
+        "ms_shade": sum(s["ms_shade"] for s in stats),
+        "paths": sum(s["paths"] for s in stats),
+    }
+
+
+def s5_roofline(gpu, dev, seed, n, spp, prof, prof_note):
+    """The instance lattice (top-level hierarchy over n^3 Translate(Group[Sphere]), what crates/openscad emits for nested
+    loops): the configuration whose culling nodes and instances come from beyond the caches."""
+    t0 = time.perf_counter()
+    sc = gpu.new_scene()
+    pkg.scenes.scad_lattice(sc, n=n, width=1920, spp=spp, depth=50)
+    sc.commit()
+    t_build = time.perf_counter() - t0
+    w, h = sc.image_size()
+    d_sum = torch.zeros(h * w * 3, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    sc.render_accumulate_device(d_sum.data_ptr(), seed=seed, stream=stream)  # warm-up (allocates the path pools)
+    torch.cuda.synchronize()
+    stats = []
+    t0 = time.perf_counter()
+    for _ in range(2):
+        stats.append(sc.render_accumulate_device(d_sum.data_ptr(), seed=seed, stream=stream, flags=pkg.bindings.RENDER_TIME_KERNELS))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = traversal_sums(stats)
+    alg = t["bvh"] * BYTES_WIDE_NODE + t["prim"] * BYTES_INSTANCE + t["seg"] * BYTES_SEGMENT_STATE
+    achieved = alg / (t["ms_trace"] * 1e-3) / 1e9
+    p5 = (prof or {}).get("s5") or {}
+    traffic = p5.get("hbm_bytes_per_segment")
+    out = {
+        "workload": f"OpenSCAD-shaped instance lattice {n}^3 (+ ground), {w}x{h}, {spp} spp, depth 50; built and committed in {t_build:.1f} s",
+        "path_samples_per_s": t["paths"] / dt,
+        "kernel": "k_extend<35, true, true, *> (instanced spheres: 4-wide culling nodes and fused instance records from memory)",
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic * t["seg"] / t["launches"] if (traffic and not prof_note) else None,
+        "algorithmic_bytes_per_launch": alg / t["launches"],
+        "avg_launch_ms": t["ms_trace"] / t["launches"],
+        "launches": t["launches"],
+        "per_segment": {"wide_nodes": t["bvh"] / t["seg"], "instance_tests": t["prim"] / t["seg"], "bytes": alg / t["seg"]},
+        "note": "achieved prices every node / instance record as a fetch from memory; the tables (180 MB) fit the 256 MB "
+                "Infinity Cache, so `traffic` (PMC: 2 x FETCH_SIZE + WRITE_SIZE beyond L2, per launch) includes cache hits",
+    }
+    assert out["frac"] <= 1.0, "S5 roofline above the HBM peak: the byte model is wrong"
+    return out
 
 
 def main():
@@ -71,6 +161,11 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-s5", action="store_true", help="skip the instance-lattice (HBM-bound) roofline leg")
+    ap.add_argument("--s5-n", type=int, default=100)
+    ap.add_argument("--s5-spp", type=int, default=64)
+    ap.add_argument("--no-rank-share", action="store_true", help="skip timing one rank's share of an 8-GPU job")
+    ap.add_argument("--simulate-rank-of", type=int, default=8, help="ranks of the job whose per-rank share is timed on this GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,17 +189,23 @@ def main():
     d_sum = torch.zeros(h * w * 3, dtype=torch.float32, device=dev)
     d_rgb8 = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    D = pkg.distributed
 
-    def step(flags=0):
-        d_sum.zero_()
-        st = sc.render_accumulate_device(
-            d_sum.data_ptr(), seed=args.seed, stratum_offset=rank, stratum_stride=world, stream=stream, flags=flags
-        )
-        if world > 1:
-            dist.reduce(d_sum, dst=0)
-        if rank == 0:
-            sc.resolve_device(d_sum.data_ptr(), w * h, d_rgb8_ptr=d_rgb8.data_ptr(), stream=stream)
-        return st
+    def make_step(n_ranks, my_rank, reduce_world, flags=0, stats_out=None):
+        def render_partial(offset, stride):
+            d_sum.zero_()
+            st = sc.render_accumulate_device(d_sum.data_ptr(), seed=args.seed, stratum_offset=offset, stratum_stride=stride, stream=stream, flags=flags)
+            if stats_out is not None:
+                stats_out.append(st)
+            return d_sum
+
+        def resolve_frame(total):
+            sc.resolve_device(total.data_ptr(), w * h, d_rgb8_ptr=d_rgb8.data_ptr(), stream=stream)
+            return d_rgb8
+
+        if reduce_world:
+            return lambda: D.frame_step(render_partial, resolve_frame, my_rank, n_ranks)
+        return lambda: render_partial(my_rank, n_ranks)  # one rank's share alone: no reduce, no resolve
 
     def fence():
         torch.cuda.synchronize()
@@ -112,13 +213,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    warm = make_step(world, rank, True)
     for _ in range(args.warmup):
-        step()
+        warm()
     fence()
-    t0 = time.perf_counter()
     stats = []
+    step = make_step(world, rank, True, flags=pkg.bindings.RENDER_TIME_KERNELS, stats_out=stats)
+    t0 = time.perf_counter()
     for _ in range(args.steps):
-        stats.append(step(flags=pkg.bindings.RENDER_TIME_KERNELS))
+        step()
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -129,14 +232,49 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = n_paths_frame * args.steps / dt
+        default_workload = args.width == 1920 and args.spp == 1024 and args.depth == 50
+        prof, prof_note = load_profile()
         # traversal-kernel roofline from this rank's launches in the timed steps
-        seg = sum(s["segments"] for s in stats)
-        bvh = sum(s["bvh_visits"] for s in stats)
-        prim = sum(s["prim_tests"] for s in stats)
-        launches = sum(s["trace_launches"] for s in stats)
-        ms_trace = sum(s["ms_trace"] for s in stats)
-        alg_bytes = bvh * BYTES_BVH_NODE + prim * BYTES_SPHERE + seg * BYTES_SEGMENT_STATE
-        achieved = alg_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else None
+        tr = traversal_sums(stats)
+        seg, launches, ms_trace = tr["seg"], tr["launches"], tr["ms_trace"]
+        lds_bytes = tr["bvh"] * BYTES_WIDE_NODE + tr["prim"] * BYTES_SPHERE + seg * BYTES_SEGMENT_STATE
+        p2 = (prof or {}).get("s2") or {}
+        ops_per_seg = p2.get("valu_lane_ops_per_segment")
+        usable = bool(ops_per_seg) and not prof_note and default_workload
+        achieved = ops_per_seg * seg / (ms_trace * 1e-3) / 1e12 if (usable and ms_trace > 0) else None
+        roofline = {
+            "kernel": "k_extend<0, true, true, *> (ordered closest-hit traversal: f32 culling of 4-wide nodes, f64 sphere tests, scene tables in LDS)",
+            "bound": "valu",
+            "achieved": achieved,
+            "peak": VALU_PEAK_TLANEOPS,
+            "unit": "Tlane-op/s",
+            "frac": achieved / VALU_PEAK_TLANEOPS if achieved else None,
+            "traffic": (p2.get("hbm_bytes_per_segment") * seg / launches) if (usable and p2.get("hbm_bytes_per_segment")) else None,
+            "definition": "achieved = vector-ALU lane-operations per ray segment (SQ_THREAD_CYCLES_VALU: active lanes x issue slots, from the "
+                          "profile) x segments of the timed launches / their summed HIP-event durations; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz. "
+                          "With two batches in flight a launch shares the device with the other batch's shading, so durations are longer than alone.",
+            "profile": {
+                "path": os.path.relpath(PROFILE_JSON, ROOT),
+                "git": (prof or {}).get("git"),
+                "kernel_source_sha256_16": (prof or {}).get("kernel_source_sha256_16"),
+                "note": prof_note or ("figures apply to the default workload only" if not default_workload else None),
+                "alone": {k: p2.get(k) for k in ("valu_busy", "lane_utilisation", "frac_of_valu_peak_alone", "avg_launch_ms_alone")},
+            },
+            "avg_launch_ms": ms_trace / launches if launches else None,
+            "launches": launches,
+            "per_segment": {
+                "wide_nodes": tr["bvh"] / seg if seg else None,
+                "prim_tests": tr["prim"] / seg if seg else None,
+                "valu_lane_ops": ops_per_seg if usable else None,
+            },
+            "segments_per_path": seg / tr["paths"] if tr["paths"] else None,
+            "trace_share_of_device_time": ms_trace / tr["ms_total"] if tr["ms_total"] else None,
+            # the north star's "traversal bandwidth": node / sphere / path-record bytes the traversal consumes per second,
+            # nearly all of them served by LDS; a rate of its own, not a fraction of any memory's peak
+            "lds_served_traversal_GBps": lds_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else None,
+        }
+        if roofline["frac"] is not None:
+            assert roofline["frac"] <= 1.0, "roofline above the vector-ALU peak: the work model is wrong"
         out = {
             "metric": "path-samples/sec (whole node), RTIOW final scene",
             "value": value,
@@ -148,7 +286,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64 geometry (hit decisions, t, points, normals) + f32 culling boxes, radiance and framebuffer",
             "data": "synthetic",
             "config": {
                 "workload": f"RTIOW final random-spheres scene (scene seed 1), {w}x{h}, {args.spp} spp ({q}x{q} strata), depth {args.depth}, one frame per step",
@@ -156,33 +294,34 @@ def main():
                 "parallelism": f"strata round-robin over {world} GPU(s), one RCCL reduce per frame",
                 "render_seed": args.seed,
             },
-            "roofline": {
-                "kernel": "k_extend<0, true, true, *> (ordered BVH traversal: f32 child-box culling, f64 sphere tests, LDS scene cache)",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": PMC_TRAFFIC_DEFAULT_WORKLOAD if (world == 1 and args.width == 1920 and args.spp == 1024 and args.depth == 50) else None,
-                "note": "achieved = algorithmic bytes (every node / sphere record counted as an HBM fetch) / kernel time; the scene "
-                        "tables are LDS-resident, so HBM only carries the path records (traffic) and the kernel is VALU-bound",
-                "algorithmic_bytes_per_launch": alg_bytes / launches if launches else None,
-                "avg_launch_ms": ms_trace / launches if launches else None,
-                "launches": launches,
-                "per_segment": {
-                    "bvh_nodes": bvh / seg if seg else None,
-                    "prim_tests": prim / seg if seg else None,
-                    "bytes": alg_bytes / seg if seg else None,
-                },
-                "segments_per_path": seg / (sum(s["paths"] for s in stats)) if stats else None,
-                "trace_share_of_device_time": ms_trace / sum(s["ms_total"] for s in stats) if stats else None,
-            },
+            "roofline": roofline,
             "device_ms_per_step": {
-                "render_call": sum(s["ms_total"] for s in stats) / args.steps,
+                "render_call": tr["ms_total"] / args.steps,
                 "traversal": ms_trace / args.steps,
-                "bin_and_shade": sum(s["ms_shade"] for s in stats) / args.steps,
+                "bin_and_shade": tr["ms_shade"] / args.steps,
             },
         }
+        if world == 1 and not args.no_rank_share and args.simulate_rank_of > 1:
+            # one rank's share of an N-GPU job on this GPU: every N-th stratum, no reduce
+            n_sim = args.simulate_rank_of
+            share = make_step(n_sim, 0, False)
+            share()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                share()
+            torch.cuda.synchronize()
+            ms_share = 1e3 * (time.perf_counter() - t0) / 3
+            out["rank_share"] = {
+                "ranks": n_sim,
+                "ms_per_share": ms_share,
+                "ms_full_frame_one_gpu": ms_per_step,
+                "implied_scaling_ceiling": ms_per_step / ms_share,
+                "note": f"strata 0, {n_sim}, {2 * n_sim}, ... of every pixel on this GPU, no reduce (24.9 MB over xGMI, < 1 ms); "
+                        f"the ceiling is T(1) / T(share), at most {n_sim}",
+            }
+        if world == 1 and not args.no_s5:
+            out["roofline_s5"] = s5_roofline(gpu, dev, args.seed, args.s5_n, args.s5_spp, prof, prof_note)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width, args.depth, args.seed)
         print(json.dumps(out))

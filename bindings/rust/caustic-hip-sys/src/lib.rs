@@ -104,6 +104,26 @@ pub struct chip_flat_scene {
     pub n_members: usize,
 }
 
+/// Tile callback of `chip_render_frame_blocks`: (user, xmin, xmax, ymin, ymax, rgb8, strata_done, strata_total).
+pub type chip_block_fn = unsafe extern "C" fn(*mut c_void, u32, u32, u32, u32, *const u8, u32, u32);
+
+// Layout of everything that crosses the ABI: the numbers of tests/abi/abi_check.c (which asserts them against the C
+// header) and of the ctypes structures in rust-raytracer_amd/bindings.py.
+macro_rules! abi_layout {
+    ($t:ty, $size:expr, $($f:ident = $off:expr),*) => {
+        const _: () = assert!(core::mem::size_of::<$t>() == $size);
+        $(const _: () = assert!(core::mem::offset_of!($t, $f) == $off);)*
+    };
+}
+abi_layout!(chip_camera_desc, 144, vertical_fov = 0, aspect_ratio = 8, image_width = 16, reserved0 = 20, look_from = 24, look_at = 48, up = 72,
+            defocus_angle = 96, focus_distance = 104, samples_per_pixel = 112, max_depth = 116, background = 120);
+abi_layout!(chip_render_opts, 40, seed = 0, stratum_offset = 8, stratum_stride = 12, xmin = 16, xmax = 20, ymin = 24, ymax = 28, strata_per_batch = 32, flags = 36);
+abi_layout!(chip_hit, 88, t = 0, pt = 8, normal = 32, u = 56, v = 64, hit = 72, leaf_id = 76, front_face = 80, material_kind = 84);
+abi_layout!(chip_stats, 80, paths = 0, segments = 8, bvh_visits = 16, prim_tests = 24, ms_total = 32, ms_trace = 40, ms_shade = 48, ms_other = 56,
+            trace_launches = 64, batches = 72);
+abi_layout!(chip_flat_node, 96, kind = 0, mat = 4, first = 8, count = 12, flags = 16, reserved = 20, v = 24);
+abi_layout!(chip_flat_scene, 32, nodes = 0, n_nodes = 8, members = 16, n_members = 24);
+
 extern "C" {
     pub fn chip_last_error() -> *const c_char;
     pub fn chip_device_count() -> c_int;
@@ -146,6 +166,15 @@ extern "C" {
     pub fn chip_render_accumulate_device(s: *mut chip_scene, opts: *const chip_render_opts, d_sum_rgb: *mut f32, stream: *mut c_void, stats: *mut chip_stats) -> c_int;
     pub fn chip_resolve_device(s: *mut chip_scene, d_sum_rgb: *const f32, npixels: usize, d_out_gamma: *mut f32, d_out_rgb8: *mut u8, stream: *mut c_void) -> c_int;
     pub fn chip_resolve_device_flags(s: *mut chip_scene, d_sum_rgb: *const f32, npixels: usize, d_out_gamma: *mut f32, d_out_rgb8: *mut u8, flags: u32, stream: *mut c_void) -> c_int;
+    /// The frame tile by tile, progressively (see caustic_hip.h); `on_block` runs on the calling thread.
+    pub fn chip_render_frame_blocks(s: *mut chip_scene, opts: *const chip_render_opts, block_size: u32, passes: u32, on_block: chip_block_fn, user: *mut c_void, stats: *mut chip_stats) -> c_int;
+    pub fn chip_write_png(path: *const c_char, width: u32, height: u32, rgb8: *const u8) -> c_int;
+    /// `chip_render_accumulate_device` without any allocation (rectangle <= `chip_noalloc_max_pixels()` pixels, max_depth <= 254).
+    pub fn chip_render_accumulate_noalloc(s: *mut chip_scene, opts: *const chip_render_opts, d_sum_rgb: *mut f32, stream: *mut c_void, stats: *mut chip_stats) -> c_int;
+    pub fn chip_noalloc_max_pixels() -> u32;
+    /// One process, several GPUs: replicate the committed scene, then render frames whose strata are dealt over the replicas.
+    pub fn chip_commit_devices(s: *mut chip_scene, devices: *const c_int, n: c_int) -> c_int;
+    pub fn chip_render_frame_multi(s: *mut chip_scene, opts: *const chip_render_opts, out_sum_rgb: *mut f32, out_rgb8: *mut u8, stats: *mut chip_stats) -> c_int;
     pub fn chip_trace_rays(s: *mut chip_scene, seed: u64, n: usize, origin: *const f64, direction: *const f64, time: *const f64, out: *mut chip_hit) -> c_int;
     pub fn chip_camera_rays(s: *mut chip_scene, seed: u64, n: usize, xyss: *const u32, rays: *mut f64) -> c_int;
     pub fn chip_dump_tree(s: *mut chip_scene, kinds: *mut i32, ids: *mut i32, boxes: *mut f64, cap: usize) -> i64;

@@ -214,6 +214,23 @@ int chip_resolve_device(chip_scene* s, const float* d_sum_rgb, size_t npixels, f
 int chip_resolve_device_flags(chip_scene* s, const float* d_sum_rgb, size_t npixels, float* d_out_gamma, uint8_t* d_out_rgb8, uint32_t flags,
                               void* stream);
 
+/* The frame delivered block by block, progressively: what the reference's front ends consume.  crates/cli cuts the
+ * frame into BLOCK_SIZE x BLOCK_SIZE tiles, renders them on worker threads and paints each finished tile
+ * (crates/cli/src/main.rs:27,83-106,165-182); the web front end's worker pool does the same with rectangles and repaints
+ * per result (webapp/frontend/src/RenderWorkerPool.ts:68-77 over crates/wasm/src/lib.rs:215-242).  A GPU renders all
+ * pixels at once, so the progression here is over samples: the strata this call covers are rendered in `passes`
+ * groups, and after each group every block_size x block_size tile of the rectangle (clipped at its edges) is handed to
+ * `on_block` with camera.rs:343-344 applied to the samples taken so far, quantised like chip_render_frame's out_rgb8
+ * (rgb8 = (xmax - xmin) * (ymax - ymin) * 3 bytes, valid during the call only).  Tiles arrive in the order the
+ * reference's workers pop them, last pushed first (main.rs:132).  After the last pass of a call that covers every
+ * stratum the tiles hold chip_render_frame's bytes.  on_block runs on the calling thread, between GPU passes. */
+typedef void (*chip_block_fn)(void* user, uint32_t xmin, uint32_t xmax, uint32_t ymin, uint32_t ymax, const uint8_t* rgb8,
+                              uint32_t strata_done, uint32_t strata_total);
+int chip_render_frame_blocks(chip_scene* s, const chip_render_opts* opts, uint32_t block_size, uint32_t passes, chip_block_fn on_block, void* user,
+                             chip_stats* stats);
+/* 8-bit RGB PNG file of a frame (crates/cli/src/main.rs:188 `img.save`); the zlib stream uses stored blocks. */
+int chip_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb8);
+
 /* chip_render_accumulate_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  This entry point has no counterpart in the reference.  It calls no hipMalloc,
  * hipFree, stream / event creation or other allocating routine: its path pool (32768 path slots with their counters,

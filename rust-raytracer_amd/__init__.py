@@ -6,4 +6,4 @@ The directory name contains a hyphen, so import it with
 `importlib.import_module("rust-raytracer_amd")`.
 """
 from . import bindings, distributed, scenes  # noqa: F401
-from .bindings import CausticError, load_gpu, gpu_device_count  # noqa: F401
+from .bindings import CausticError, load_gpu, gpu_device_count, write_png  # noqa: F401

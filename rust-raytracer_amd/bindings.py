@@ -98,6 +98,10 @@ NODE_KIND_NAMES = {0: "bvh", 1: "sphere", 2: "quad", 3: "group", 4: "translate",
  NODE_SCALE) = range(12)  # CHIP_NODE_* of include/caustic_hip.h
 
 
+# chip_block_fn: (user, xmin, xmax, ymin, ymax, rgb8, strata_done, strata_total)
+BLOCK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32)
+
+
 class CausticError(RuntimeError):
     pass
 
@@ -194,6 +198,8 @@ class Backend:
             "resolve_device": (i, [p, p, C.c_size_t, p, p, p]),
             "scene_from_flat": (C.c_int64, [p, C.POINTER(FlatScene), pi32]),
             "commit_devices": (i, [p, pi32, i]),
+            "render_frame_blocks": (i, [p, C.POINTER(RenderOpts), C.c_uint32, C.c_uint32, BLOCK_FN, p, C.POINTER(Stats)]),
+            "write_png": (i, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]),
             "render_frame_multi": (i, [p, C.POINTER(RenderOpts), p, C.POINTER(C.c_uint8), C.POINTER(Stats)]),
             "render_accumulate_noalloc": (i, [p, C.POINTER(RenderOpts), p, p, C.POINTER(Stats)]),
             "noalloc_max_pixels": (C.c_uint32, []),
@@ -491,6 +497,19 @@ class Scene:
         self._call("render_accumulate_noalloc", C.byref(o), C.c_void_p(d_sum_ptr), C.c_void_p(stream), C.byref(st))
         return st.as_dict()
 
+    def render_frame_blocks(self, on_block, block_size=10, passes=1, seed=1, stratum_offset=0, stratum_stride=1, rect=None, flags=0):
+        """Renders progressively and calls on_block(xmin, xmax, ymin, ymax, rgb8[h, w, 3], strata_done, strata_total) per tile
+        and pass (crates/cli's block loop / the web worker pool's per-result repaint)."""
+        o = self._opts(seed, stratum_offset, stratum_stride, rect, 0, flags)
+        st = Stats()
+
+        def thunk(_user, xmin, xmax, ymin, ymax, data, done, total):
+            n = (xmax - xmin) * (ymax - ymin) * 3
+            on_block(xmin, xmax, ymin, ymax, np.ctypeslib.as_array(data, shape=(n,)).reshape(ymax - ymin, xmax - xmin, 3).copy(), done, total)
+
+        self._call("render_frame_blocks", C.byref(o), block_size, passes, BLOCK_FN(thunk), None, C.byref(st))
+        return st.as_dict()
+
     def commit_devices(self, devices):
         a = np.ascontiguousarray(devices, dtype=np.int32)
         return self._call("commit_devices", _ptr(a, C.c_int32), int(a.size))
@@ -545,6 +564,15 @@ def load_gpu() -> Backend:
             raise CausticError(f"{GPU_LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` (hipcc, gfx950)")
         _gpu_backend = Backend(C.CDLL(GPU_LIB_PATH), "chip_", "libcaustic_hip")
     return _gpu_backend
+
+
+def write_png(path: str, rgb8: np.ndarray):
+    """crates/cli/src/main.rs:188: the frame as an 8-bit RGB PNG file (host-side, no GPU involved)."""
+    be = load_gpu()
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, c = a.shape
+    assert c == 3
+    be.check(be.fn("write_png")(os.fsencode(path), w, h, _ptr(a, C.c_uint8)))
 
 
 def gpu_device_count() -> int:

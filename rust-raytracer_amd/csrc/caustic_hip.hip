@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <atomic>
 #include <functional>
 #include <memory>
@@ -1387,6 +1388,125 @@ int chip_render_frame_multi(chip_scene* s, const chip_render_opts* opts, float* 
     }
   }
   return frame_outputs(s, D0, npix, opts->flags, out_sum_rgb, out_rgb8);
+}
+
+int chip_render_frame_blocks(chip_scene* s, const chip_render_opts* opts, uint32_t block_size, uint32_t passes, chip_block_fn on_block, void* user,
+                             chip_stats* stats) {
+  NEED_SCENE;
+  if (!opts || !on_block) return fail("null argument");
+  if (block_size == 0) return fail("block_size must be > 0");
+  RenderPlan pl;
+  if (plan_render(s, opts, pl)) return -1;
+  DeviceState& D = s->dev;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(D.device));
+  const size_t npix = (size_t)pl.rw * pl.rh;
+  HIP_TRY(D.frame_sum.reserve(npix * 3));
+  HIP_TRY(D.frame_rgb8.reserve(npix * 3));
+  HIP_TRY(hipMemsetAsync(D.frame_sum.p, 0, npix * 3 * sizeof(float), nullptr));
+  const uint32_t total = pl.s_count;
+  passes = std::max<uint32_t>(1, std::min<uint32_t>(passes, std::max<uint32_t>(total, 1)));
+  std::vector<uint8_t> rgb8(npix * 3), blockbuf;
+  chip_stats sum{};
+  uint32_t done = 0;
+  for (uint32_t p = 0; p < passes; p++) {
+    // pass p adds strata [p * total / passes, (p + 1) * total / passes) of this call's list to the running sums
+    const uint32_t i0 = (uint32_t)((uint64_t)p * total / passes), i1 = (uint32_t)((uint64_t)(p + 1) * total / passes);
+    RenderPlan sub = pl;
+    sub.s_first = pl.s_first + i0 * pl.s_stride;
+    sub.s_count = i1 - i0;
+    chip_stats st{};
+    if (sub.s_count && render_into(s, D, opts, sub, D.frame_sum.p, nullptr, &st, false)) return -1;
+    done = i1;
+    sum.paths += st.paths; sum.segments += st.segments; sum.bvh_visits += st.bvh_visits; sum.prim_tests += st.prim_tests;
+    sum.ms_total += st.ms_total; sum.ms_trace += st.ms_trace; sum.ms_shade += st.ms_shade; sum.trace_launches += st.trace_launches;
+    sum.batches += st.batches;
+    // camera.rs:343-344 with the samples taken so far (after the last pass of a call that covers every stratum this is
+    // pixel_samples_scale itself, so the final blocks are chip_render_frame's bytes)
+    const double scale = 1.0 / (double)std::max<uint32_t>(done, 1);
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(npix * 3)), dim3(CHIP_BLOCK), 0, nullptr, D.frame_sum.p, npix * 3, scale, (float*)nullptr, D.frame_rgb8.p,
+                       (opts->flags & CHIP_RENDER_QUANTISE_255) ? 255.0 : 255.999);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rgb8.data(), D.frame_rgb8.p, npix * 3, hipMemcpyDeviceToHost));
+    // the blocks of crates/cli/src/main.rs:83-106 (rows of block_size x block_size tiles, clipped at the image edge),
+    // handed over in the order its workers pop them: last pushed first (main.rs:132)
+    const uint32_t nbx = (pl.rw + block_size - 1) / block_size, nby = (pl.rh + block_size - 1) / block_size;
+    for (uint32_t b = nbx * nby; b-- > 0;) {
+      const uint32_t bx = b % nbx, by = b / nbx;
+      const uint32_t x0 = bx * block_size, x1 = std::min(x0 + block_size, pl.rw), y0 = by * block_size, y1 = std::min(y0 + block_size, pl.rh);
+      blockbuf.resize((size_t)(x1 - x0) * (y1 - y0) * 3);
+      for (uint32_t y = y0; y < y1; y++)
+        std::memcpy(blockbuf.data() + (size_t)(y - y0) * (x1 - x0) * 3, rgb8.data() + ((size_t)y * pl.rw + x0) * 3, (size_t)(x1 - x0) * 3);
+      on_block(user, pl.xmin + x0, pl.xmin + x1, pl.ymin + y0, pl.ymin + y1, blockbuf.data(), done, total);
+    }
+  }
+  if (stats) *stats = sum;
+  return 0;
+}
+
+// ---- PNG (crates/cli/src/main.rs:188 saves the frame with the image crate; this writer emits the same pixels as an
+// 8-bit RGB PNG whose zlib stream uses stored blocks, which every PNG reader accepts)
+static uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {
+  static uint32_t table[256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    ready = true;
+  }
+  for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+  return crc;
+}
+static void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+  v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+static void put_chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data) {
+  put_be32(out, (uint32_t)data.size());
+  const size_t at = out.size();
+  out.insert(out.end(), type, type + 4);
+  out.insert(out.end(), data.begin(), data.end());
+  put_be32(out, crc32_update(0xFFFFFFFFu, out.data() + at, out.size() - at) ^ 0xFFFFFFFFu);
+}
+int chip_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb8) {
+  if (!path || !rgb8 || width == 0 || height == 0) return fail("chip_write_png: bad argument");
+  if ((uint64_t)width * height * 3 + height > 0x7FFFFFFFull) return fail("chip_write_png: image too large");
+  std::vector<uint8_t> raw;  // scanlines, each behind filter type 0
+  raw.reserve((size_t)height * (1 + (size_t)width * 3));
+  for (uint32_t y = 0; y < height; y++) {
+    raw.push_back(0);
+    raw.insert(raw.end(), rgb8 + (size_t)y * width * 3, rgb8 + (size_t)(y + 1) * width * 3);
+  }
+  std::vector<uint8_t> z = {0x78, 0x01};  // zlib header: deflate, 32 K window, no preset dictionary
+  uint32_t a = 1, b = 0;                  // Adler-32 of the raw bytes
+  for (size_t pos = 0; pos < raw.size();) {
+    const size_t n = std::min<size_t>(65535, raw.size() - pos);
+    z.push_back(pos + n == raw.size() ? 1 : 0);  // stored block, BFINAL on the last one
+    z.push_back((uint8_t)n); z.push_back((uint8_t)(n >> 8));
+    z.push_back((uint8_t)~n); z.push_back((uint8_t)(~n >> 8));
+    z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+    for (size_t i = 0; i < n; i++) {
+      a = (a + raw[pos + i]) % 65521u;
+      b = (b + a) % 65521u;
+    }
+    pos += n;
+  }
+  put_be32(z, (b << 16) | a);
+  std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  std::vector<uint8_t> ihdr;
+  put_be32(ihdr, width);
+  put_be32(ihdr, height);
+  ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});  // 8 bits per channel, colour type 2 (RGB), deflate, adaptive filtering, no interlace
+  put_chunk(out, "IHDR", ihdr);
+  put_chunk(out, "IDAT", z);
+  put_chunk(out, "IEND", {});
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(std::string("chip_write_png: cannot open ") + path);
+  const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+  if (fclose(f) != 0 || !ok) return fail(std::string("chip_write_png: write to ") + path + " failed");
+  return 0;
 }
 
 int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, const double* d, const double* tm, chip_hit* out) {

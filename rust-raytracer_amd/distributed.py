@@ -41,3 +41,11 @@ def render_frame_sharded(render_partial, rank: int, world: int) -> torch.Tensor:
     result on rank 0 is the whole frame's sum (other ranks keep their partial sums)."""
     t = render_partial(rank, world)
     return reduce_frame(t, world)
+
+
+def frame_step(render_partial, resolve_frame, rank: int, world: int):
+    """One whole frame of the N-rank job, the step bench.py times: every rank renders its strata, the sums are
+    reduced onto rank 0, rank 0 resolves (`resolve_frame(sum)`; camera.rs:343-344 and the 8-bit quantisation).
+    Returns rank 0's resolved frame (None on the other ranks)."""
+    total = render_frame_sharded(render_partial, rank, world)
+    return resolve_frame(total) if rank == 0 else None

@@ -682,3 +682,44 @@ def test_textures_on_every_primitive_under_instances(pkg, gpu, oracle):
     assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 3e-3
     fast, _, _ = sg.render_frame(seed=3)
     assert (np.abs(fast.astype(np.float64) - img_o) > 2e-3 * (1.0 + np.abs(img_o))).mean() < 1.5e-2
+
+
+@pytest.mark.gpu
+def test_progressive_blocks_end_in_the_frame(pkg, gpu, tmp_path):
+    """chip_render_frame_blocks: the tiles of crates/cli/src/main.rs:83-106 (10 x 10, clipped at the edges, last pushed
+    first), refined over passes; the last pass's tiles assemble chip_render_frame's bytes, and the PNG of that frame
+    reads back the same."""
+    from PIL import Image
+
+    sc = pkg.scenes.build(gpu, "cornell_box", width=75, spp=16, depth=8)
+    w, h = sc.image_size()
+    _, want, _ = sc.render_frame(seed=6, want_rgb8=True)
+    seen, frames = [], {}
+
+    def on_block(xmin, xmax, ymin, ymax, rgb8, done, total):
+        seen.append((xmin, xmax, ymin, ymax, done, total))
+        frames.setdefault(done, np.zeros((h, w, 3), dtype=np.uint8))[ymin:ymax, xmin:xmax] = rgb8
+
+    st = sc.render_frame_blocks(on_block, block_size=10, passes=4, seed=6)
+    assert st["paths"] == w * h * 16
+    assert sorted(frames) == [4, 8, 12, 16] and all(t == 16 for *_, t in seen)
+    per_pass = [b for b in seen if b[4] == 4]
+    assert len(per_pass) == 8 * 8 and per_pass[0][:4] == (70, 75, 70, 75) and per_pass[-1][:4] == (0, 10, 0, 10)
+    assert np.array_equal(frames[16], want)
+    # earlier passes show the same picture with fewer samples
+    err = [np.abs(frames[d].astype(int) - want.astype(int)).mean() for d in (4, 8, 12, 16)]
+    assert err[0] > err[1] > err[2] > err[3] == 0.0 and err[0] < 40
+    path = str(tmp_path / "out.png")
+    pkg.write_png(path, frames[16])
+    assert np.array_equal(np.asarray(Image.open(path).convert("RGB")), want)
+    # a rectangle with the wasm caller's quantisation
+    rect = (12, 40, 30, 55)
+    _, want_r, _ = sc.render_frame(seed=6, rect=rect, want_rgb8=True, flags=pkg.bindings.RENDER_QUANTISE_255)
+    got_r = np.zeros_like(want_r)
+
+    def on_rect(xmin, xmax, ymin, ymax, rgb8, done, total):
+        if done == total:
+            got_r[ymin - rect[2]:ymax - rect[2], xmin - rect[0]:xmax - rect[0]] = rgb8
+
+    sc.render_frame_blocks(on_rect, block_size=16, passes=2, seed=6, rect=rect, flags=pkg.bindings.RENDER_QUANTISE_255)
+    assert np.array_equal(got_r, want_r)

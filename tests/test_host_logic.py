@@ -124,3 +124,57 @@ def test_image_height_rule(gpu_lib, oracle):
             sc = be.new_scene()
             sc.set_camera(image_width=width, aspect_ratio=aspect)
             assert sc.image_size() == (width, want)
+
+
+def test_abi_layouts_agree(pkg):
+    """The structs that cross the C ABI, three ways: include/caustic_hip.h compiled as plain C with tests/abi/abi_check.c's
+    static assertions, the const assertions of bindings/rust/caustic-hip-sys/src/lib.rs (read as text: there is no Rust
+    toolchain here), and the ctypes structures the tests drive the library with."""
+    import ctypes as C
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "abi", "abi_check.c")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(root, "include"), src])
+    text = open(src).read()
+    c_sizes = {m.group(1): int(m.group(2)) for m in re.finditer(r"SIZE\((\w+), (\d+)\);", text)}
+    c_offs = {(m.group(1), m.group(2)): int(m.group(3)) for m in re.finditer(r"OFF\((\w+), (\w+), (\d+)\);", text)}
+    assert len(c_sizes) == 6 and len(c_offs) > 50
+    rust = open(os.path.join(root, "bindings", "rust", "caustic-hip-sys", "src", "lib.rs")).read()
+    r_sizes, r_offs = {}, {}
+    for m in re.finditer(r"abi_layout!\((\w+), (\d+), ([^;]*)\);", rust):
+        r_sizes[m.group(1)] = int(m.group(2))
+        for f in re.finditer(r"(\w+) = (\d+)", m.group(3)):
+            r_offs[(m.group(1), f.group(1))] = int(f.group(2))
+    assert r_sizes == c_sizes and r_offs == c_offs
+    B = pkg.bindings
+    ct = {"chip_camera_desc": B.CameraDesc, "chip_render_opts": B.RenderOpts, "chip_stats": B.Stats, "chip_flat_scene": B.FlatScene}
+    for name, cls in ct.items():
+        assert C.sizeof(cls) == c_sizes[name]
+        for fname, _ in cls._fields_:
+            assert getattr(cls, fname).offset == c_offs[(name, fname)], (name, fname)
+    assert B.HIT_DTYPE.itemsize == c_sizes["chip_hit"] and B.FLAT_NODE_DTYPE.itemsize == c_sizes["chip_flat_node"]
+    for dt, name in ((B.HIT_DTYPE, "chip_hit"), (B.FLAT_NODE_DTYPE, "chip_flat_node")):
+        for fname in dt.names:
+            assert dt.fields[fname][1] == c_offs[(name, fname)], (name, fname)
+    # every function the Rust crate declares exists in the header, and the other way round
+    header = open(os.path.join(root, "include", "caustic_hip.h")).read()
+    h_fns = set(re.findall(r"\b(chip_\w+)\(", header))
+    r_fns = set(re.findall(r"pub fn (chip_\w+)\(", rust))
+    assert h_fns == r_fns, (sorted(h_fns - r_fns), sorted(r_fns - h_fns))
+
+
+def test_png_writer_round_trips(pkg, gpu_lib, tmp_path):
+    """chip_write_png (crates/cli/src/main.rs:188's img.save): a reader gets the same pixels back.  Host-side only."""
+    from PIL import Image
+
+    rng = np.random.default_rng(3)
+    for w, h in ((1, 1), (7, 5), (300, 257)):  # the last one needs more than one 64 KB stored block
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        path = str(tmp_path / f"t{w}x{h}.png")
+        pkg.write_png(path, img)
+        back = np.asarray(Image.open(path).convert("RGB"))
+        assert back.shape == img.shape and np.array_equal(back, img)
+    with pytest.raises(pkg.CausticError, match="cannot open"):
+        pkg.write_png(str(tmp_path / "no_such_dir" / "x.png"), img)

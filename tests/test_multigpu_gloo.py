@@ -1,6 +1,7 @@
 """The N > 1 path (strata dealt round-robin over ranks, one reduce per frame, resolve on rank 0) run with
 world_size 2 over gloo on the CPU; the per-rank renderer here is the oracle, the sharding / reduce /
-resolve code is the product's (rust-raytracer_amd/distributed.py, the same code bench.py uses)."""
+resolve code is the product's: `distributed.frame_step`, the function bench.py's timed step calls (there with the
+GPU library as renderer and resolver)."""
 import os
 import sys
 
@@ -29,11 +30,18 @@ def _worker(rank, world, port, tmpdir):
         img, _, _ = sc.render_frame(seed=4, stratum_offset=offset, stratum_stride=stride, sum_dtype=np.float64)
         return torch.from_numpy(img)
 
-    total = D.render_frame_sharded(partial, rank, world)
+    kept = {}
+
+    def resolve(total):
+        kept["sum"] = total
+        return D.resolve(total, sc.sqrt_spp())
+
+    rgb8 = D.frame_step(partial, resolve, rank, world)
     if rank == 0:
-        rgb8 = D.resolve(total, sc.sqrt_spp())
-        np.save(os.path.join(tmpdir, "sum.npy"), total.numpy())
+        np.save(os.path.join(tmpdir, "sum.npy"), kept["sum"].numpy())
         np.save(os.path.join(tmpdir, "rgb8.npy"), rgb8.numpy())
+    else:
+        assert rgb8 is None
     dist.barrier()
     dist.destroy_process_group()
 
