@@ -770,6 +770,8 @@ static int upload_scene(chip_scene* s, DeviceState& D, const Flat& F) {
     D.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   if (ensure_resources(D)) return -1;
+  // the traversal addresses culling nodes by 32-bit byte offsets of 128 bytes each
+  if (F.wnodes.size() >= ((size_t)1 << 25)) return fail("scene has 2^25 or more culling nodes");
   HIP_TRY(D.d_bvh.upload(F.bvh));
   HIP_TRY(D.d_wnodes.upload(F.wnodes));
   HIP_TRY(D.d_spheres.upload(F.spheres));

@@ -210,9 +210,14 @@ struct TravRay {
   double dd;        // direction.length_squared() of d (sphere.rs:102)
   double time;
   // f32 culling form of the ray (ordered traversal): the slab distance of a box plane b is
-  // fma(b, m, c) with m ~ 1/d and c ~ -o/d, biased so that entry distances come out too small and exit
-  // distances too large; capf is the current closest hit rounded up.
-  float m_lo[3], m_hi[3], c_lo[3], c_hi[3];
+  // fma(b, m, c) with m ~ 1/d and c ~ -o/d.  Per axis the ray enters a box through its low plane when d > 0 and
+  // through its high plane otherwise, so which plane is the near one is a property of the ray: far16 is 16 where
+  // the near plane is the high one (a byte offset between a record's low and high plane words, and the index of
+  // the near plane in a (low, high) pair when divided by 16).  (m_n, c_n) are biased so that the near plane's
+  // distance comes out too small, (m_f, c_f) so that the far plane's comes out too large; capf is the current
+  // closest hit rounded up.
+  float m_n[3], m_f[3], c_n[3], c_f[3];
+  uint32_t far16[3];
   float capf;
   uint32_t best_mat;  // mat word of the closest primitive so far
 };
@@ -226,6 +231,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) u32x4_t* lds_cv4_t;
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x2_t* lds_u2_t;
+typedef __attribute__((address_space(3))) unsigned char* lds_b_t;
 __device__ inline uint4 lds_read4(uint32_t i) {
   lds_cv4_t p = (lds_cv4_t)g_lds;
   u32x4_t t = p[i];
@@ -241,17 +247,21 @@ struct TravStack {
   uint32_t overflow;
   uint32_t redo;    // ordered traversal met a ray it must not handle (see traverse): rerun it literally
   int lds_cap;      // entries kept in LDS
-  uint32_t shift;   // log2 of the LDS words between consecutive entries of one lane (= threads per block)
+  uint32_t stride8; // bytes between consecutive entries of one lane (8 x threads per block; below 2^24)
 };
 // Read-only copy of the hottest scene records in LDS: the first n_bvh culling nodes (the tables are in
-// breadth-first order, so these are the top of the tree) and the first n_sph spheres.  Each record is split
-// into its 16-byte components (seven of a culling node, four of a sphere) stored in separate arrays
-// (component k of record i at [k * cap + i]), which spreads the lanes of a wave over the LDS banks.
+// breadth-first order, so these are the top of the tree) and the first n_sph spheres.  A sphere is split into
+// its four 16-byte components stored in separate arrays (component k of record i at [k * cap + i]), which
+// spreads the lanes of a wave over the LDS banks; a culling node is stored as three arrays of (low, high) plane
+// word pairs, one per axis, followed by the array of child words (see load_wnode).
 struct NodeCache {
   uint32_t bvh_off, sph_off;  // first uint4 of the BVH / sphere component arrays in g_lds
   uint32_t n_bvh, n_sph;      // records cached
   uint32_t cap_bvh, cap_sph;  // array strides (records)
 };
+__device__ inline lds_u2_t st_entry(const TravStack& s) {  // entry s.sp of this lane's column: one 24-bit multiply-add
+  return (lds_u2_t)((lds_b_t)s.lds + __umul24((uint32_t)s.sp, s.stride8));
+}
 struct TravCounters {
   uint32_t bvh, prim;
 };
@@ -264,7 +274,7 @@ __device__ inline void st_push(TravStack& s, uint32_t v, float t = 0.0f) {
   if (s.sp < s.lds_cap) {
     u32x2_t e;
     e.x = v; e.y = __float_as_uint(t);
-    s.lds[s.sp << s.shift] = e;
+    (*st_entry(s)) = e;
   } else if (s.sp < s.lds_cap + CHIP_STACK_OVF) {
     s.ovf[2 * (s.sp - s.lds_cap)] = v;
     s.ovf[2 * (s.sp - s.lds_cap) + 1] = __float_as_uint(t);
@@ -274,7 +284,7 @@ __device__ inline void st_push(TravStack& s, uint32_t v, float t = 0.0f) {
 __device__ inline uint32_t st_pop_raw(TravStack& s, int base, bool with_t) {
   if (s.sp <= base) return NREF_NONE;
   s.sp--;
-  return s.sp < s.lds_cap ? s.lds[s.sp << s.shift].x : s.ovf[2 * (s.sp - s.lds_cap)];
+  return s.sp < s.lds_cap ? (*st_entry(s)).x : s.ovf[2 * (s.sp - s.lds_cap)];
 }
 template <bool WITH_T>
 __device__ inline uint32_t st_pop(TravStack& s, int base, float capf = 0.0f) {
@@ -284,7 +294,7 @@ __device__ inline uint32_t st_pop(TravStack& s, int base, float capf = 0.0f) {
     uint32_t v;
     float t = 0.0f;
     if (s.sp < s.lds_cap) {
-      const u32x2_t e = s.lds[s.sp << s.shift];
+      const u32x2_t e = (*st_entry(s));
       v = e.x;
       t = __uint_as_float(e.y);
     } else {
@@ -332,26 +342,48 @@ __device__ inline void load_sphere(const DScene& S, const NodeCache& C, uint32_t
   n.mat = d.z;
 }
 
+// A culling node as one ray sees it: per axis the four children's near planes and far planes (TravRay::far16 says
+// which of the record's low / high plane words is which for this ray).
 struct WNodeRec {
-  float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];
+  float near_x[4], far_x[4], near_y[4], far_y[4], near_z[4], far_z[4];
   nref_t child[4];
 };
 __device__ inline void u4_to_f4(const uint4& u, float* f) {
   f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
 }
+__device__ inline uint4 lds_read4_at(uint32_t byte) {
+  typedef const volatile __attribute__((address_space(3))) unsigned char* lds_cvb_t;
+  lds_cv4_t p = (lds_cv4_t)((lds_cvb_t)g_lds + byte);
+  u32x4_t t = *p;
+  uint4 v;
+  v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+  return v;
+}
+// In a 128-byte record the low and high plane words of an axis are 16 bytes apart in one 32-byte aligned pair, and
+// the LDS copy keeps the pairs together ([axis][record][low, high], then the child words), so the far plane's
+// address is the near plane's with bit 4 flipped.  Global records are addressed with 32-bit byte offsets from the
+// table's base (the host refuses tables of 2^25 nodes or more).
 template <bool CACHE>
-__device__ inline void load_wnode(const DScene& S, const NodeCache& C, uint32_t idx, WNodeRec& n) {
+__device__ inline void load_wnode(const DScene& S, const NodeCache& C, uint32_t idx, const TravRay& r, WNodeRec& n) {
   uint4 q[CHIP_WNODE_U4];
   if (CACHE && idx < C.n_bvh) {
-    const uint32_t i = C.bvh_off + idx;
-#pragma unroll
-    for (int k = 0; k < CHIP_WNODE_U4; k++) q[k] = lds_read4(i + k * C.cap_bvh);
+    const uint32_t axis = C.cap_bvh << 5, base = C.bvh_off << 4;
+    const uint32_t b = idx << 5;
+    const uint32_t nx = b + r.far16[0] + base, ny = b + r.far16[1] + (base + axis), nz = b + r.far16[2] + (base + 2u * axis);
+    q[0] = lds_read4_at(nx); q[1] = lds_read4_at(nx ^ 16u);
+    q[2] = lds_read4_at(ny); q[3] = lds_read4_at(ny ^ 16u);
+    q[4] = lds_read4_at(nz); q[5] = lds_read4_at(nz ^ 16u);
+    q[6] = lds_read4_at((idx << 4) + (base + 3u * axis));
   } else {
-    const uint4* p = reinterpret_cast<const uint4*>(S.wnodes + idx);
-#pragma unroll
-    for (int k = 0; k < CHIP_WNODE_U4; k++) q[k] = p[k];
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(S.wnodes);
+    const uint32_t b = idx << 7;
+    const uint32_t nx = b + r.far16[0], ny = b + r.far16[1] + 32u, nz = b + r.far16[2] + 64u;
+    q[0] = *reinterpret_cast<const uint4*>(p + nx); q[1] = *reinterpret_cast<const uint4*>(p + (nx ^ 16u));
+    q[2] = *reinterpret_cast<const uint4*>(p + ny); q[3] = *reinterpret_cast<const uint4*>(p + (ny ^ 16u));
+    q[4] = *reinterpret_cast<const uint4*>(p + nz); q[5] = *reinterpret_cast<const uint4*>(p + (nz ^ 16u));
+    q[6] = *reinterpret_cast<const uint4*>(p + (b + 96u));
   }
-  u4_to_f4(q[0], n.lo_x); u4_to_f4(q[1], n.hi_x); u4_to_f4(q[2], n.lo_y); u4_to_f4(q[3], n.hi_y); u4_to_f4(q[4], n.lo_z); u4_to_f4(q[5], n.hi_z);
+  u4_to_f4(q[0], n.near_x); u4_to_f4(q[1], n.far_x); u4_to_f4(q[2], n.near_y); u4_to_f4(q[3], n.far_y); u4_to_f4(q[4], n.near_z); u4_to_f4(q[5], n.far_z);
   n.child[0] = q[6].x; n.child[1] = q[6].y; n.child[2] = q[6].z; n.child[3] = q[6].w;
 }
 
@@ -362,11 +394,12 @@ __device__ inline void load_wnode(const DScene& S, const NodeCache& C, uint32_t 
 #define CHIP_CULL_TMIN 0.00099999f             // just below the 0.001 ray minimum of camera.rs:264
 #define CHIP_CULL_BIG 3.0e38f
 __device__ inline void cull_slab(const float* b, const TravRay& r, float& entry, float& exit) {
-  const float x0 = fmaf(b[0], r.m_lo[0], r.c_lo[0]), x1 = fmaf(b[1], r.m_hi[0], r.c_hi[0]);
-  const float y0 = fmaf(b[2], r.m_lo[1], r.c_lo[1]), y1 = fmaf(b[3], r.m_hi[1], r.c_hi[1]);
-  const float z0 = fmaf(b[4], r.m_lo[2], r.c_lo[2]), z1 = fmaf(b[5], r.m_hi[2], r.c_hi[2]);
-  entry = fmaxf(fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1)), CHIP_CULL_TMIN);
-  exit = fminf(fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)), r.capf);
+  const uint32_t sx = r.far16[0] >> 4, sy = r.far16[1] >> 4, sz = r.far16[2] >> 4;
+  const float x0 = fmaf(b[sx], r.m_n[0], r.c_n[0]), x1 = fmaf(b[1u - sx], r.m_f[0], r.c_f[0]);
+  const float y0 = fmaf(b[2u + sy], r.m_n[1], r.c_n[1]), y1 = fmaf(b[3u - sy], r.m_f[1], r.c_f[1]);
+  const float z0 = fmaf(b[4u + sz], r.m_n[2], r.c_n[2]), z1 = fmaf(b[5u - sz], r.m_f[2], r.c_f[2]);
+  entry = fmaxf(fmaxf(fmaxf(x0, y0), z0), CHIP_CULL_TMIN);
+  exit = fminf(fminf(fminf(x1, y1), z1), r.capf);
 }
 __device__ inline float f32_above(double v) {  // an f32 >= v (one ulp of slack)
   const float f = (float)v;
@@ -376,26 +409,25 @@ __device__ inline float f32_below(double v) {
   const float f = (float)v;
   return fmaf(-fabsf(f), 1.1920929e-07f, f);
 }
-// Culling form for the ray currently in r.o / r.d.
+// Culling form for the ray currently in r.o / r.d.  Every direction component is finite and well away from zero here
+// (has_zero_component() sends the other rays to the literal traversal), so each axis culls and a box with its low planes
+// above its high planes (an unused child slot) is missed whatever the ray.
 __device__ inline void ray_set_cull(TravRay& r) {
   const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     const float invf = __frcp_rn((float)d[a]);
-    if (fabsf(invf) <= 1.0e18f) {
-      const bool pos = invf > 0.0f;
-      const float s = pos ? CHIP_CULL_DELTA : -CHIP_CULL_DELTA;
-      const float ml = invf * (1.0f - s), mh = invf * (1.0f + s);
-      const double cl = -(o[a] * (double)ml), ch = -(o[a] * (double)mh);
-      r.m_lo[a] = ml;
-      r.m_hi[a] = mh;
-      r.c_lo[a] = pos ? f32_below(cl) : f32_above(cl);  // the low plane is the entry plane iff d > 0
-      r.c_hi[a] = pos ? f32_above(ch) : f32_below(ch);
-    } else {  // direction component (nearly) zero: this axis does not cull
-      r.m_lo[a] = r.m_hi[a] = 0.0f;
-      r.c_lo[a] = -CHIP_CULL_BIG;
-      r.c_hi[a] = CHIP_CULL_BIG;
-    }
+    const bool pos = invf > 0.0f;
+    const float s = pos ? CHIP_CULL_DELTA : -CHIP_CULL_DELTA;
+    const float ml = invf * (1.0f - s), mh = invf * (1.0f + s);  // multipliers of the low / the high plane
+    const double cl = -(o[a] * (double)ml), ch = -(o[a] * (double)mh);
+    const float c_low = pos ? f32_below(cl) : f32_above(cl);  // the low plane is the near one iff d > 0
+    const float c_high = pos ? f32_above(ch) : f32_below(ch);
+    r.m_n[a] = pos ? ml : mh;
+    r.c_n[a] = pos ? c_low : c_high;
+    r.m_f[a] = pos ? mh : ml;
+    r.c_f[a] = pos ? c_high : c_low;
+    r.far16[a] = pos ? 0u : 16u;
   }
 }
 
@@ -629,7 +661,12 @@ __device__ inline void ray_to_space(const DScene& S, nref_t x, V3 wo, V3 wd, V3&
 // origin lies exactly on a box plane, and its compare chain then rejects or accepts the box depending on
 // the sign of the zero; the culling test of the ordered traversal does not reproduce that, so such rays
 // are traced by the literal interpretation instead.
-__device__ inline bool has_zero_component(V3 d) { return !(d.x != 0.0 && d.y != 0.0 && d.z != 0.0) || d.x != d.x || d.y != d.y || d.z != d.z; }
+// The same goes for components so small or so large that their f32 reciprocal is not an ordinary number: the culling
+// test relies on every axis having a finite non-zero slope.  NaN components fail the comparisons and land here too.
+__device__ inline bool has_zero_component(V3 d) {
+  const double lo = 1.0e-18, hi = 1.0e18;
+  return !(fabs(d.x) > lo && fabs(d.x) < hi && fabs(d.y) > lo && fabs(d.y) < hi && fabs(d.z) > lo && fabs(d.z) < hi);
+}
 
 // Takes the ray straight into the space of `inner`, the innermost of a run of nested instances (the instances in
 // between have no effect of their own: translate.rs:26-38, rotate.rs:137-150, scale.rs:93-115 only transform the ray
@@ -675,7 +712,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       // down, which keeps the pop-time test conservative.
       while (NREF_KIND(node) == NK_BVH) {
         WNodeRec n;
-        load_wnode<CACHE>(S, C, NREF_INDEX(node), n);
+        load_wnode<CACHE>(S, C, NREF_INDEX(node), r, n);
 #if CHIP_TRAV_PROFILE  /* counts wave-level loop trips instead of per-lane visits */
         if (__lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) cnt.bvh++;
 #else
@@ -684,12 +721,12 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
         uint32_t key[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const float x0 = fmaf(n.lo_x[k], r.m_lo[0], r.c_lo[0]), x1 = fmaf(n.hi_x[k], r.m_hi[0], r.c_hi[0]);
-          const float y0 = fmaf(n.lo_y[k], r.m_lo[1], r.c_lo[1]), y1 = fmaf(n.hi_y[k], r.m_hi[1], r.c_hi[1]);
-          const float z0 = fmaf(n.lo_z[k], r.m_lo[2], r.c_lo[2]), z1 = fmaf(n.hi_z[k], r.m_hi[2], r.c_hi[2]);
-          const float en = fmaxf(fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1)), CHIP_CULL_TMIN);
-          const float ex = fminf(fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)), r.capf);
-          key[k] = (en <= ex && n.child[k] != NREF_NONE) ? ((__float_as_uint(en) & ~3u) | (uint32_t)k) : 0xFFFFFFFFu;
+          const float x0 = fmaf(n.near_x[k], r.m_n[0], r.c_n[0]), x1 = fmaf(n.far_x[k], r.m_f[0], r.c_f[0]);
+          const float y0 = fmaf(n.near_y[k], r.m_n[1], r.c_n[1]), y1 = fmaf(n.far_y[k], r.m_f[1], r.c_f[1]);
+          const float z0 = fmaf(n.near_z[k], r.m_n[2], r.c_n[2]), z1 = fmaf(n.far_z[k], r.m_f[2], r.c_f[2]);
+          const float en = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x0, y0), z0), CHIP_CULL_TMIN);
+          const float ex = fminf(__builtin_fminf(__builtin_fminf(x1, y1), z1), r.capf);
+          key[k] = en <= ex ? ((__float_as_uint(en) & ~3u) | (uint32_t)k) : 0xFFFFFFFFu;  // an unused slot never passes
         }
         // sorting network on four keys
 #define CHIP_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
@@ -1490,12 +1527,15 @@ struct CacheDesc {
   uint32_t n_bvh, n_sph;     // leading BVH nodes / spheres copied into LDS (0 = no cache)
   uint32_t stack_entries;    // per-lane stack entries kept in LDS
 };
-// Threads per block of the traversal kernel: with the LDS scene cache one block owns a whole CU's LDS.
+// Threads per block of the traversal kernel: with the LDS scene cache one block owns a whole CU's LDS.  Twelve
+// waves (768 threads) leave each of them 168 VGPRs, which the variants with rotated quads need to stay out of
+// scratch memory; the variants for spheres and for sphere instances fit (or nearly fit) sixteen waves' 128 and run
+// faster with the extra waves than without the few spills.
 #ifndef CHIP_EXT_BLOCK_QUADS
-#define CHIP_EXT_BLOCK_QUADS 1024  // block of the cached kernel for scenes with more than bare spheres
+#define CHIP_EXT_BLOCK_QUADS 768
 #endif
 __host__ __device__ constexpr int extend_block(uint32_t F, bool CACHE) {
-  return CACHE ? ((F & TF_MEDIA_ANY) ? 512 : (F == 0 ? 1024 : CHIP_EXT_BLOCK_QUADS)) : CHIP_BLOCK;
+  return CACHE ? ((F & TF_MEDIA_ANY) ? 512 : ((F == 0 || (F & TF_NO_QUADROT)) ? 1024 : CHIP_EXT_BLOCK_QUADS)) : CHIP_BLOCK;
 }
 // Waves per SIMD the traversal kernel is register-allocated for.  The LDS-cached sphere-scene kernel asks for 6
 // (at most 80 VGPRs) although only 4 of its own waves fit beside its LDS: the registers it leaves free are
@@ -1521,7 +1561,11 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
     for (uint32_t i = threadIdx.x; i < cd.n_bvh; i += blockDim.x) {
       const uint4* p = reinterpret_cast<const uint4*>(S.wnodes + i);
 #pragma unroll
-      for (int k = 0; k < CHIP_WNODE_U4; k++) g_lds[k * cd.n_bvh + i] = p[k];
+      for (int a = 0; a < 3; a++) {
+        g_lds[2u * (a * cd.n_bvh + i)] = p[2 * a];
+        g_lds[2u * (a * cd.n_bvh + i) + 1u] = p[2 * a + 1];
+      }
+      g_lds[6u * cd.n_bvh + i] = p[6];
     }
     const uint32_t so = (uint32_t)CHIP_WNODE_U4 * cd.n_bvh;
     for (uint32_t i = threadIdx.x; i < cd.n_sph; i += blockDim.x) {
@@ -1541,7 +1585,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
   st.redo = 0;
   st.sp = 0;
   st.lds_cap = (int)cd.stack_entries;
-  st.shift = 31 - __clz((int)blockDim.x);
+  st.stride8 = 8u * blockDim.x;
   TravCounters cnt{0, 0};
   uint32_t nseg = 0;
   bool has = false;  // this lane holds a ray (traversing or finished)
@@ -1975,7 +2019,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P,
   st.overflow = 0;
   st.redo = 0;
   st.lds_cap = CHIP_STACK_LDS;
-  st.shift = 31 - __clz(CHIP_BLOCK);
+  st.stride8 = 8u * CHIP_BLOCK;
   const NodeCache none{0, 0, 0, 0, 0, 0};
   TravCounters cnt{0, 0};
   for (uint32_t i = gtid; i < n; i += gridDim.x * blockDim.x) {

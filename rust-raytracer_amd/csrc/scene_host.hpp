@@ -777,15 +777,23 @@ struct HostScene {
   }
   static void set_cull_box(float* out, const Box6& b) {
     const float big = std::numeric_limits<float>::max();
-    auto clampf = [&](float v) { return v > big ? big : (v < -big ? -big : v); };
+    // a NaN bound does not constrain (the plane moves out to where every ray passes)
+    auto clampf = [&](float v, float nan_as) { return v != v ? nan_as : (v > big ? big : (v < -big ? -big : v)); };
     for (int a = 0; a < 3; a++) {
-      out[2 * a] = clampf(f32_down(b.v[2 * a]));
-      out[2 * a + 1] = clampf(f32_up(b.v[2 * a + 1]));
+      out[2 * a] = clampf(f32_down(b.v[2 * a]), -big);
+      out[2 * a + 1] = clampf(f32_up(b.v[2 * a + 1]), big);
     }
   }
-  static void set_empty_box(float* out) {
+  // The culling test takes a ray's near plane on each axis by the sign of its direction and never orders the two
+  // plane distances itself, so a box whose low planes lie above its high planes is missed by every ray and a box
+  // spanning the whole f32 range is hit by every ray.
+  static void set_unreachable_box(float* out) {
     const float big = std::numeric_limits<float>::max();
     for (int a = 0; a < 3; a++) { out[2 * a] = big; out[2 * a + 1] = -big; }
+  }
+  static void set_unbounded_box(float* out) {
+    const float big = std::numeric_limits<float>::max();
+    for (int a = 0; a < 3; a++) { out[2 * a] = -big; out[2 * a + 1] = big; }
   }
   // Splits leaves[lo, hi) (hi - lo >= 2) and returns the split position.
   static size_t sah_split(std::vector<SahLeaf>& leaves, size_t lo, size_t hi) {
@@ -862,7 +870,9 @@ struct HostScene {
     for (size_t i = 0; i < n; i++) {
       DWNode& w = F.wnodes[i];
       std::memset(&w, 0, sizeof(w));
-      for (int k = 0; k < 4; k++) w.child[k] = NREF_NONE;
+      float none[6];
+      set_unreachable_box(none);
+      for (int k = 0; k < 4; k++) set_wide_child(w, k, NREF_NONE, none);  // an unused slot is culled like a missed box
     }
     std::vector<SahLeaf> leaves;
     std::vector<uint32_t> slots, stack;
@@ -898,11 +908,10 @@ struct HostScene {
       leaves.erase(std::remove_if(leaves.begin(), leaves.end(), [](const SahLeaf& l) { return !(l.box.v[0] <= l.box.v[1]); }), leaves.end());
       DWNode& wroot = F.wnodes[root];
       if (leaves.empty()) {
-        // an empty hierarchy: its reference children (two empty Groups) stand in, behind boxes every ray hits (the
-        // slab test orders each axis's two plane distances with min / max, so an inverted box is hit by every ray);
+        // an empty hierarchy: its reference children (two empty Groups) stand in, behind boxes every ray hits;
         // visiting them does nothing, whereas a node without children would read as the end of the traversal
         float e[6];
-        set_empty_box(e);
+        set_unbounded_box(e);
         set_wide_child(wroot, 0, F.bvh[root].left, e);
         set_wide_child(wroot, 1, F.bvh[root].right, e);
         continue;
