@@ -24,6 +24,16 @@
 #ifndef CHIP_REFILL_THRESH_B0
 #define CHIP_REFILL_THRESH_B0 1  // the same for camera rays: never, so that a wave always computes 64 camera rays at a time
 #endif
+// The descent loop of the ordered traversal goes on while at least 1 / DEN of the wave's lanes that still have a ray
+// are at culling nodes (see traverse); 0 = until none is.  Measured per scene family: bare spheres gain the most
+// from a small share, sphere instances from a larger one, and the variants whose other node kinds are expensive
+// (rotated quads, media) lose from leaving the loop early at all.
+#ifndef CHIP_DESCENT_DEN_SPHERES
+#define CHIP_DESCENT_DEN_SPHERES 8u
+#endif
+#ifndef CHIP_DESCENT_DEN_INSTANCES
+#define CHIP_DESCENT_DEN_INSTANCES 4u
+#endif
 #ifndef CHIP_REFILL_THRESH
 #define CHIP_REFILL_THRESH 48  // a traversing wave refills its idle lanes once fewer than this many are busy
 #endif
@@ -703,6 +713,7 @@ __device__ __noinline__ void traverse_boundary(const DScene& S, nref_t start, Tr
 template <uint32_t F, bool YIELD, bool CACHE, bool ORD>
 __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng,
                          TravStack& st, const int base, TravCounters& cnt, int yield_below) {
+  constexpr uint32_t DEN = F == 0 ? CHIP_DESCENT_DEN_SPHERES : ((F & TF_NO_QUADROT) ? CHIP_DESCENT_DEN_INSTANCES : 0u);
   for (;;) {
     // BVH descent (bvh.rs:58-76): test the node's own box over (tmin, best_t); left first, right deferred.
     if (ORD) {
@@ -710,7 +721,19 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       // nearest on top.  A child's sort key is its entry distance (positive, so its bits order like the value) with
       // the two lowest bits replaced by the child's slot; the distance a deferred child carries is thereby rounded
       // down, which keeps the pop-time test conservative.
-      while (NREF_KIND(node) == NK_BVH) {
+      // The wave stays in the descent loop while enough of its lanes are at culling nodes; once most of them wait
+      // at something else it lets go, handles those (the lanes still at culling nodes sit that out) and comes back.
+      // Either phase thereby runs with a fair share of the wave's lanes, whereas waiting for the last descending
+      // lane leaves most of them idle for most of the loop's trips.
+      for (;;) {
+        const bool inner = NREF_KIND(node) == NK_BVH;
+        if (DEN != 0u) {
+          const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner)), n_here = (uint32_t)__popcll(__ballot(1));
+          if (n_inner == 0u || n_inner * DEN < n_here) break;
+          if (!inner) continue;
+        } else if (!inner) {
+          break;
+        }
         WNodeRec n;
         load_wnode<CACHE>(S, C, NREF_INDEX(node), r, n);
 #if CHIP_TRAV_PROFILE  /* counts wave-level loop trips instead of per-lane visits */
@@ -768,7 +791,9 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
     r.best_mat = (matw);                                                      \
     if (ORD) r.capf = f32_above(best_t);                                      \
   }
-    if (kind == NK_SPHERE) {
+    if (ORD && DEN != 0u && kind == NK_BVH) {
+      // still descending: sits this round out
+    } else if (kind == NK_SPHERE) {
       double t;
 #if CHIP_TRAV_PROFILE
       if (__lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) cnt.prim++;
@@ -970,7 +995,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       r.best_mat = hit_medium ? m.mat : outer_mat;
       if (ORD && hit_medium) r.capf = f32_above(best_t);
     }
-    node = st_pop<ORD>(st, base, r.capf);
+    if (!ORD || DEN == 0u || kind != NK_BVH) node = st_pop<ORD>(st, base, r.capf);
     if (YIELD && ORD && __popcll(__ballot(1)) < yield_below) break;  // (the literal form is too heavy to gain from refills)
   }
 #undef CHIP_TAKE
