@@ -141,7 +141,6 @@ struct DeviceState {
   DevBuf<DQuad> d_quads;
   DevBuf<DGroup> d_groups;
   DevBuf<nref_t> d_gchild;
-  DevBuf<float> d_gbox;
   DevBuf<DTranslate> d_translates;
   DevBuf<DRotate> d_rotates;
   DevBuf<DScale> d_scales;
@@ -168,7 +167,7 @@ struct DeviceState {
   PathPool noalloc_pool{};
 
   void release_tables() {
-    d_bvh.release(); d_wnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release(); d_gbox.release();
+    d_bvh.release(); d_wnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release();
     d_translates.release(); d_rotates.release(); d_scales.release(); d_discs.release(); d_cones.release(); d_media.release(); d_xchain.release(); d_materials.release();
     d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
     uploaded = false;
@@ -778,7 +777,6 @@ static int upload_scene(chip_scene* s, DeviceState& D, const Flat& F) {
   HIP_TRY(D.d_quads.upload(F.quads));
   HIP_TRY(D.d_groups.upload(F.groups));
   HIP_TRY(D.d_gchild.upload(F.gchild));
-  HIP_TRY(D.d_gbox.upload(F.gbox));
   HIP_TRY(D.d_translates.upload(F.translates));
   HIP_TRY(D.d_rotates.upload(F.rotates));
   HIP_TRY(D.d_scales.upload(F.scales));
@@ -792,12 +790,13 @@ static int upload_scene(chip_scene* s, DeviceState& D, const Flat& F) {
   HIP_TRY(D.d_texels.upload(s->host.texels));
   HIP_TRY(D.d_lights.upload(F.lights));
   DScene& T = D.dscene;
-  T.bvh = D.d_bvh.p; T.wnodes = D.d_wnodes.p; T.spheres = D.d_spheres.p; T.quads = D.d_quads.p; T.groups = D.d_groups.p; T.gchild = D.d_gchild.p; T.gbox = D.d_gbox.p;
+  T.bvh = D.d_bvh.p; T.wnodes = D.d_wnodes.p; T.spheres = D.d_spheres.p; T.quads = D.d_quads.p; T.groups = D.d_groups.p; T.gchild = D.d_gchild.p;
   T.translates = D.d_translates.p; T.rotates = D.d_rotates.p; T.scales = D.d_scales.p; T.discs = D.d_discs.p; T.cones = D.d_cones.p;
   T.media = D.d_media.p; T.xchain = D.d_xchain.p;
   T.materials = D.d_materials.p; T.textures = D.d_textures.p; T.perlins = D.d_perlins.p; T.texels = D.d_texels.p;
   T.lights = D.d_lights.p;
   T.root = F.root;
+  T.ord_root = F.ord_root;
   T.n_lights = (uint32_t)F.lights.size();
   T.has_lights = F.has_lights;
   T.lights_is_group = F.lights_is_group;

@@ -104,6 +104,9 @@ struct alignas(128) DTranslate {
   // Where a traversal that enters this node continues: through a run of nested instances (each the other's only
   // content, e.g. Translate(Rotate(Box))) straight into the innermost one's space (enter_xform) and child.
   nref_t enter_xform, enter_child;
+  // Where the ordered traversal continues instead of enter_child: the same node, unless that is a Group, whose
+  // children it finds in a culling tree of their own.
+  nref_t ord_child;
   uint32_t sphere_mat;  // with only_sphere: that sphere's mat word and, below, its geometry, so that testing the
   double sc[3], sdc[3], sr;  // instance reads this one 128-byte record instead of two records one after the other
 };
@@ -113,7 +116,8 @@ struct alignas(8) DRotate {
   nref_t child;
   nref_t parent_xform;
   uint32_t chain_first, chain_len;
-  nref_t enter_xform, enter_child;  // see DTranslate
+  nref_t enter_xform, enter_child, ord_child;  // see DTranslate
+  uint32_t pad;
 };
 
 struct alignas(8) DScale {
@@ -121,7 +125,8 @@ struct alignas(8) DScale {
   nref_t child;
   nref_t parent_xform;
   uint32_t chain_first, chain_len;
-  nref_t enter_xform, enter_child;  // see DTranslate
+  nref_t enter_xform, enter_child, ord_child;  // see DTranslate
+  uint32_t pad;
 };
 
 struct alignas(8) DMedium {
@@ -180,7 +185,6 @@ struct DScene {
   const DQuad* quads;
   const DGroup* groups;
   const nref_t* gchild;
-  const float* gbox;  // 6 floats per gchild entry: the child's bounding box rounded outward to f32 (culling only)
   const DTranslate* translates;
   const DRotate* rotates;
   const DScale* scales;
@@ -194,6 +198,7 @@ struct DScene {
   const uint8_t* texels;
   const DLight* lights;
   nref_t root;
+  nref_t ord_root;  // the ordered traversal's starting node (differs from root when that is a Group)
   uint32_t n_lights;
   uint32_t has_lights;       // SceneData.lights is Some
   uint32_t lights_is_group;  // lights root is a Group (one member is picked per sample)

@@ -403,14 +403,6 @@ __device__ inline void load_wnode(const DScene& S, const NodeCache& C, uint32_t 
 #define CHIP_CULL_DELTA 9.5367431640625e-07f  // 2^-20: covers the f32 rounding of 1/d, m and the multiply-add
 #define CHIP_CULL_TMIN 0.00099999f             // just below the 0.001 ray minimum of camera.rs:264
 #define CHIP_CULL_BIG 3.0e38f
-__device__ inline void cull_slab(const float* b, const TravRay& r, float& entry, float& exit) {
-  const uint32_t sx = r.far16[0] >> 4, sy = r.far16[1] >> 4, sz = r.far16[2] >> 4;
-  const float x0 = fmaf(b[sx], r.m_n[0], r.c_n[0]), x1 = fmaf(b[1u - sx], r.m_f[0], r.c_f[0]);
-  const float y0 = fmaf(b[2u + sy], r.m_n[1], r.c_n[1]), y1 = fmaf(b[3u - sy], r.m_f[1], r.c_f[1]);
-  const float z0 = fmaf(b[4u + sz], r.m_n[2], r.c_n[2]), z1 = fmaf(b[5u - sz], r.m_f[2], r.c_f[2]);
-  entry = fmaxf(fmaxf(fmaxf(x0, y0), z0), CHIP_CULL_TMIN);
-  exit = fminf(fminf(fminf(x1, y1), z1), r.capf);
-}
 __device__ inline float f32_above(double v) {  // an f32 >= v (one ulp of slack)
   const float f = (float)v;
   return fmaf(fabsf(f), 1.1920929e-07f, f);
@@ -815,7 +807,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       double t;
       cnt.prim++;
       if (cone_hit(S.cones[idx], r, tmin, best_t, t)) { CHIP_TAKE(node, t, S.cones[idx].mat) }
-    } else if ((F & TF_QUADS) && (kind == NK_GROUP || kind == NK_GROUP_CONT)) {
+    } else if (!ORD && (F & TF_QUADS) && (kind == NK_GROUP || kind == NK_GROUP_CONT)) {
       // group.rs:44-54: children in order, each over the shrinking interval.  Primitive
       // children are tested inline; any other child is descended into, leaving a
       // (position, continuation) pair on the stack.
@@ -826,13 +818,6 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       for (; pos < g.count; pos++) {
         nref_t c = S.gchild[g.first + pos];
         uint32_t ck = NREF_KIND(c);
-        if (ORD && !(F & TF_NO_QUADROT) && g.count > 1) {
-          // a child whose box the ray cannot reach before the closest hit so far holds nothing for it (a box's six
-          // quads: at most two can be hit); an only child's box is the group's own, tested on the way here
-          float en, ex;
-          cull_slab(S.gbox + 6u * (g.first + pos), r, en, ex);
-          if (!(en <= ex)) continue;
-        }
         if (ck == NK_SPHERE) {
           double t;
           cnt.prim++;
@@ -893,7 +878,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
           node = NREF_NONE;
           return;
         }
-        node = t.enter_child;
+        node = ORD ? t.ord_child : t.enter_child;
         continue;
       }
     } else if ((F & TF_XFORM) && !(F & TF_NO_QUADROT) && kind == NK_ROTATE) {
@@ -904,7 +889,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
           node = NREF_NONE;
           return;
         }
-        node = t.enter_child;
+        node = ORD ? t.ord_child : t.enter_child;
         continue;
       }
       r.o = mat_mulT(t.m, r.o);
@@ -915,7 +900,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
         return;
       }
       ray_set_inv<ORD>(r);
-      node = t.child;
+      node = ORD ? t.ord_child : t.child;
       continue;
     } else if ((F & TF_EXT) && kind == NK_SCALE) {
       const DScale& t = S.scales[idx];
@@ -925,7 +910,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
           node = NREF_NONE;
           return;
         }
-        node = t.enter_child;
+        node = ORD ? t.ord_child : t.enter_child;
         continue;
       }
       r.o = mat_mul(t.inv, r.o);
@@ -936,7 +921,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
         return;
       }
       ray_set_inv<ORD>(r);
-      node = t.child;
+      node = ORD ? t.ord_child : t.child;
       continue;
     } else if ((F & TF_XFORM) && (kind == NK_EXIT_TRANSLATE || kind == NK_EXIT_ROTATE || ((F & TF_EXT) && kind == NK_EXIT_SCALE))) {
       nref_t px = kind == NK_EXIT_TRANSLATE ? S.translates[idx].parent_xform
@@ -1691,7 +1676,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
             if (B0) rng.draw = tries;  // rides to the hit record: the bounce-0 shade pass rebuilds the camera ray from it
             best_t = INFINITY;
             best = NREF_NONE;
-            node = S.root;
+            node = ORD ? S.ord_root : S.root;
             st.sp = 0;
             has = true;
           }
@@ -2066,7 +2051,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P,
     nref_t best = NREF_NONE;
     st.sp = 0;
     st.redo = 0;
-    nref_t node = S.root;
+    nref_t node = literal ? S.root : S.ord_root;
     if constexpr (ORD) {
       if (!literal) traverse<F, false, false, true>(S, none, node, r, 0.001, best_t, best, rng, st, 0, cnt);
       if (st.redo) {  // handed back by the ordered traversal: start over in the reference's order

@@ -105,6 +105,7 @@ struct Flat {
   uint32_t has_lights = 0, lights_is_group = 0;
   uint32_t loose_geometry = 0;  // some primitive of the world is not bounded by its own box
   uint32_t n_wide = 0;          // culling nodes in use: wnodes[0 .. n_wide)
+  nref_t ord_root = NREF_NONE;  // where the ordered traversal starts: root, or the culling tree of a Group root's children
 };
 
 struct HostScene {
@@ -732,10 +733,11 @@ struct HostScene {
       F.bvh_is_root.swap(ir);
     }
     F.root = remap(F.root);
+    F.ord_root = remap(F.ord_root);
     for (nref_t& c : F.gchild) c = remap(c);
-    for (DTranslate& t : F.translates) { t.child = remap(t.child); t.enter_child = remap(t.enter_child); }
-    for (DRotate& t : F.rotates) { t.child = remap(t.child); t.enter_child = remap(t.enter_child); }
-    for (DScale& t : F.scales) { t.child = remap(t.child); t.enter_child = remap(t.enter_child); }
+    for (DTranslate& t : F.translates) { t.child = remap(t.child); t.enter_child = remap(t.enter_child); t.ord_child = remap(t.ord_child); }
+    for (DRotate& t : F.rotates) { t.child = remap(t.child); t.enter_child = remap(t.enter_child); t.ord_child = remap(t.ord_child); }
+    for (DScale& t : F.scales) { t.child = remap(t.child); t.enter_child = remap(t.enter_child); t.ord_child = remap(t.ord_child); }
     for (DMedium& m : F.media) m.boundary = remap(m.boundary);
   }
 
@@ -864,16 +866,23 @@ struct HostScene {
     int left = -1, right = -1;  // -1: a leaf holding `ref`
     nref_t ref = NREF_NONE;
   };
+  static void init_wnode(DWNode& w) {
+    std::memset(&w, 0, sizeof(w));
+    float none[6];
+    set_unreachable_box(none);
+    for (int k = 0; k < 4; k++) set_wide_child(w, k, NREF_NONE, none);  // an unused slot is culled like a missed box
+  }
+  // The culling trees of the ordered traversal.  Every BoundingVolumeHierarchy gets one over its members, and a Group
+  // is opened: its children become members of the tree it sits in (or, for a Group that is the content of an
+  // instance or the world itself, of a tree of their own), because the closest hit among a Group's children
+  // (group.rs:44-54) does not depend on the order they are tried in once exact ties go by the reference's visiting
+  // order.  The ordered traversal thereby never meets a Group, only culling nodes, primitives, instances and media.
+  // Trees that need more nodes than their hierarchy has table slots (or have no hierarchy) get slots appended to both
+  // tables; the reference-order table's entries there are never visited.
   static void build_wnodes(Flat& F) {
-    const size_t n = F.bvh.size();
-    F.wnodes.resize(n);
-    for (size_t i = 0; i < n; i++) {
-      DWNode& w = F.wnodes[i];
-      std::memset(&w, 0, sizeof(w));
-      float none[6];
-      set_unreachable_box(none);
-      for (int k = 0; k < 4; k++) set_wide_child(w, k, NREF_NONE, none);  // an unused slot is culled like a missed box
-    }
+    const size_t n0 = F.bvh.size();
+    F.wnodes.resize(n0);
+    for (size_t i = 0; i < n0; i++) init_wnode(F.wnodes[i]);
     std::vector<SahLeaf> leaves;
     std::vector<uint32_t> slots, stack;
     std::vector<BinNode> bin;
@@ -881,48 +890,53 @@ struct HostScene {
     std::vector<Job> jobs;
     struct WJob { int bin; uint32_t slot; };
     std::vector<WJob> queue;
-    for (size_t root = 0; root < n; root++) {
-      if (!F.bvh_is_root[root]) continue;
-      // members and table slots of this hierarchy: walk its reference nodes
-      leaves.clear();
-      slots.clear();
-      stack.assign(1, (uint32_t)root);
-      while (!stack.empty()) {
-        uint32_t i = stack.back();
-        stack.pop_back();
-        slots.push_back(i);
-        const DBvhNode& b = F.bvh[i];
-        for (int side = 0; side < 2; side++) {
-          nref_t c = side == 0 ? b.left : b.right;
-          if (side == 1 && b.right == b.left) break;  // a single member is stored twice (bvh.rs:27-28)
-          if (NREF_KIND(c) == NK_BVH && !F.bvh_is_root[NREF_INDEX(c)]) { stack.push_back(NREF_INDEX(c)); continue; }
-          SahLeaf l;
-          l.ref = c;
-          l.box = F.bvh_child_box[side][i];
-          for (int a = 0; a < 3; a++) l.c[a] = 0.5 * (l.box.v[2 * a] + l.box.v[2 * a + 1]);
-          leaves.push_back(l);
+    auto new_slot = [&]() -> uint32_t {
+      DBvhNode b;
+      std::memset(&b, 0, sizeof(b));
+      b.left = b.right = NREF_NONE;
+      F.bvh.push_back(b);
+      F.wnodes.push_back(DWNode{});
+      init_wnode(F.wnodes.back());
+      return (uint32_t)(F.bvh.size() - 1);
+    };
+    // a member of the tree being built; Groups are opened (explicit work list: Groups nest)
+    struct Member { nref_t ref; Box6 box; };
+    std::vector<Member> open;
+    auto add_member = [&](nref_t ref, const Box6& box) {
+      open.assign(1, Member{ref, box});
+      while (!open.empty()) {
+        const Member m = open.back();
+        open.pop_back();
+        if (NREF_KIND(m.ref) == NK_GROUP) {
+          const DGroup& g = F.groups[NREF_INDEX(m.ref)];
+          for (uint32_t j = g.count; j-- > 0;) {
+            Member c;
+            c.ref = F.gchild[g.first + j];
+            for (int a = 0; a < 6; a++) c.box.v[a] = (double)F.gbox[6 * (size_t)(g.first + j) + a];
+            open.push_back(c);
+          }
+          continue;
         }
+        if (!(m.box.v[0] <= m.box.v[1])) continue;  // an empty box (an empty hierarchy, bvh.rs:23-26) holds nothing
+        SahLeaf l;
+        l.ref = m.ref;
+        l.box = m.box;
+        for (int a = 0; a < 3; a++) l.c[a] = 0.5 * (l.box.v[2 * a] + l.box.v[2 * a + 1]);
+        leaves.push_back(l);
       }
-      std::sort(slots.begin(), slots.end());
-      // drop members with an empty box (the two empty Groups of an empty hierarchy, bvh.rs:23-26)
-      leaves.erase(std::remove_if(leaves.begin(), leaves.end(), [](const SahLeaf& l) { return !(l.box.v[0] <= l.box.v[1]); }), leaves.end());
-      DWNode& wroot = F.wnodes[root];
-      if (leaves.empty()) {
-        // an empty hierarchy: its reference children (two empty Groups) stand in, behind boxes every ray hits;
-        // visiting them does nothing, whereas a node without children would read as the end of the traversal
-        float e[6];
-        set_unbounded_box(e);
-        set_wide_child(wroot, 0, F.bvh[root].left, e);
-        set_wide_child(wroot, 1, F.bvh[root].right, e);
-        continue;
-      }
+    };
+    // the tree over `leaves` (at least one), its root in slot slots[0], further nodes in the following slots and,
+    // when those run out, in appended ones
+    auto build_tree = [&]() {
+      const uint32_t root = slots[0];
       if (leaves.size() == 1) {
-        // the reference holds a single member as both children and visits it twice (bvh.rs:27-28); the second visit
-        // finds what the first one found (a ConstantMedium's two samples are taken in its one visit, DMedium::tests)
+        // (a hierarchy over a single member holds it as both children and visits it twice, bvh.rs:27-28; the second
+        // visit finds what the first one found, and a ConstantMedium's two samples are taken in its one visit,
+        // DMedium::tests)
         float b[6];
         set_cull_box(b, leaves[0].box);
-        set_wide_child(wroot, 0, leaves[0].ref, b);
-        continue;
+        set_wide_child(F.wnodes[root], 0, leaves[0].ref, b);
+        return;
       }
       // binary tree, explicit work list (a chain of uneven splits can be as deep as it is long)
       bin.clear();
@@ -948,9 +962,9 @@ struct HostScene {
         jobs.push_back(Job{job.lo, mid, l});
         jobs.push_back(Job{mid, job.hi, r});
       }
-      // breadth-first fold; wide node k of this hierarchy takes the k-th smallest slot (top levels first)
+      // breadth-first fold; wide node k of this tree takes the k-th smallest slot (top levels first)
       queue.clear();
-      queue.push_back(WJob{0, slots[0]});
+      queue.push_back(WJob{0, root});
       size_t next_slot = 1;
       for (size_t q = 0; q < queue.size(); q++) {
         const WJob job = queue[q];
@@ -965,27 +979,64 @@ struct HostScene {
               if (a > best_area) { best_area = a; best = k; }
             }
           if (best < 0) break;
-          const int open = kids[best];
-          kids[best] = bin[open].left;
-          kids[nk++] = bin[open].right;
+          const int opened = kids[best];
+          kids[best] = bin[opened].left;
+          kids[nk++] = bin[opened].right;
         }
-        DWNode& w = F.wnodes[job.slot];
         for (int k = 0; k < nk; k++) {
           const BinNode& c = bin[kids[k]];
           nref_t ref;
           if (c.left < 0) {
             ref = c.ref;
           } else {
-            const uint32_t slot = slots[next_slot++];
+            const uint32_t slot = next_slot < slots.size() ? slots[next_slot++] : new_slot();
             ref = NREF(NK_BVH, slot);
             queue.push_back(WJob{kids[k], slot});
           }
           float b[6];
           set_cull_box(b, c.box);
-          set_wide_child(w, k, ref, b);
+          set_wide_child(F.wnodes[job.slot], k, ref, b);  // (indexed anew: new_slot() may have moved the table)
         }
       }
+    };
+    for (size_t root = 0; root < n0; root++) {
+      if (!F.bvh_is_root[root]) continue;
+      // members and table slots of this hierarchy: walk its reference nodes
+      leaves.clear();
+      slots.clear();
+      stack.assign(1, (uint32_t)root);
+      while (!stack.empty()) {
+        uint32_t i = stack.back();
+        stack.pop_back();
+        slots.push_back(i);
+        for (int side = 0; side < 2; side++) {
+          const DBvhNode& b = F.bvh[i];
+          nref_t c = side == 0 ? b.left : b.right;
+          if (side == 1 && b.right == b.left) break;  // a single member is stored twice (bvh.rs:27-28)
+          if (NREF_KIND(c) == NK_BVH && !F.bvh_is_root[NREF_INDEX(c)]) { stack.push_back(NREF_INDEX(c)); continue; }
+          add_member(c, F.bvh_child_box[side][i]);
+        }
+      }
+      std::sort(slots.begin(), slots.end());
+      if (leaves.empty()) continue;  // nothing to hit: the root keeps its four unreachable slots
+      build_tree();
     }
+    // Groups that are not members of a hierarchy: the content of an instance, or the world
+    auto tree_of_group = [&](nref_t ref) -> nref_t {
+      if (NREF_KIND(ref) != NK_GROUP) return ref;
+      leaves.clear();
+      Box6 all{{-kInf, kInf, -kInf, kInf, -kInf, kInf}};
+      add_member(ref, all);
+      if (leaves.empty()) return ref;  // an empty Group: the ordered traversal passes over it
+      slots.assign(1, new_slot());
+      build_tree();
+      return NREF(NK_BVH, slots[0]);
+    };
+    for (DTranslate& t : F.translates) t.ord_child = t.only_sphere != NREF_NONE ? t.enter_child : tree_of_group(t.enter_child);
+    for (DRotate& t : F.rotates) t.ord_child = tree_of_group(t.enter_child);
+    for (DScale& t : F.scales) t.ord_child = tree_of_group(t.enter_child);
+    F.ord_root = tree_of_group(F.root);
+    const size_t n = F.bvh.size();
     for (int k = 0; k < 2; k++) { F.bvh_child_box[k].clear(); F.bvh_child_box[k].shrink_to_fit(); }
     F.bvh_is_root.clear();
     // The slots that hold culling nodes move to the front of the tables (hierarchy roots keep one index in both
