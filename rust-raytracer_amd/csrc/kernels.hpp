@@ -26,13 +26,20 @@
 #endif
 // The descent loop of the ordered traversal goes on while at least 1 / DEN of the wave's lanes that still have a ray
 // are at culling nodes (see traverse); 0 = until none is.  Measured per scene family: bare spheres gain the most
-// from a small share, sphere instances from a larger one, and the variants whose other node kinds are expensive
-// (rotated quads, media) lose from leaving the loop early at all.
+// from a small share, sphere instances from a larger one, the variant with media a little, and the one for rotated
+// quads without media loses from leaving the loop early at all.
 #ifndef CHIP_DESCENT_DEN_SPHERES
 #define CHIP_DESCENT_DEN_SPHERES 8u
 #endif
 #ifndef CHIP_DESCENT_DEN_INSTANCES
 #define CHIP_DESCENT_DEN_INSTANCES 4u
+#endif
+#ifndef CHIP_DESCENT_DEN_MEDIA
+#define CHIP_DESCENT_DEN_MEDIA 8u
+#endif
+// Waves per SIMD the full shade kernel (every material, texture and light kind) is register-allocated for.
+#ifndef CHIP_SHADE_FULL_WAVES
+#define CHIP_SHADE_FULL_WAVES 1
 #endif
 #ifndef CHIP_REFILL_THRESH
 #define CHIP_REFILL_THRESH 48  // a traversing wave refills its idle lanes once fewer than this many are busy
@@ -705,7 +712,7 @@ __device__ __noinline__ void traverse_boundary(const DScene& S, nref_t start, Tr
 template <uint32_t F, bool YIELD, bool CACHE, bool ORD>
 __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng,
                          TravStack& st, const int base, TravCounters& cnt, int yield_below) {
-  constexpr uint32_t DEN = F == 0 ? CHIP_DESCENT_DEN_SPHERES : ((F & TF_NO_QUADROT) ? CHIP_DESCENT_DEN_INSTANCES : 0u);
+  constexpr uint32_t DEN = F == 0 ? CHIP_DESCENT_DEN_SPHERES : ((F & TF_NO_QUADROT) ? CHIP_DESCENT_DEN_INSTANCES : ((F & TF_MEDIA) ? CHIP_DESCENT_DEN_MEDIA : 0u));
   for (;;) {
     // BVH descent (bvh.rs:58-76): test the node's own box over (tmin, best_t); left first, right deferred.
     if (ORD) {
@@ -1538,14 +1545,14 @@ struct CacheDesc {
   uint32_t stack_entries;    // per-lane stack entries kept in LDS
 };
 // Threads per block of the traversal kernel: with the LDS scene cache one block owns a whole CU's LDS.  Twelve
-// waves (768 threads) leave each of them 168 VGPRs, which the variants with rotated quads need to stay out of
-// scratch memory; the variants for spheres and for sphere instances fit (or nearly fit) sixteen waves' 128 and run
-// faster with the extra waves than without the few spills.
-#ifndef CHIP_EXT_BLOCK_QUADS
-#define CHIP_EXT_BLOCK_QUADS 768
+// waves (768 threads) leave each of them 168 VGPRs, which the variant with media needs to stay mostly out of scratch
+// memory; the other variants fit (or nearly fit) sixteen waves' 128 and run faster with the extra waves than
+// without the few spills.
+#ifndef CHIP_EXT_BLOCK_MEDIA
+#define CHIP_EXT_BLOCK_MEDIA 768
 #endif
 __host__ __device__ constexpr int extend_block(uint32_t F, bool CACHE) {
-  return CACHE ? ((F & TF_MEDIA_ANY) ? 512 : ((F == 0 || (F & TF_NO_QUADROT)) ? 1024 : CHIP_EXT_BLOCK_QUADS)) : CHIP_BLOCK;
+  return CACHE ? ((F & TF_MEDIA_ANY) ? 512 : ((F & TF_MEDIA) ? CHIP_EXT_BLOCK_MEDIA : 1024)) : CHIP_BLOCK;
 }
 // Waves per SIMD the traversal kernel is register-allocated for.  The LDS-cached sphere-scene kernel asks for 6
 // (at most 80 VGPRs) although only 4 of its own waves fit beside its LDS: the registers it leaves free are
@@ -1854,7 +1861,7 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
 // B0: the instantiation for bounce 0, whose entries are the batch's paths in order with their camera rays
 // recomputed and the identity as radiance map; kept apart so that neither variant pays registers for the other.
 template <bool FAST, bool LEAN, bool EXT, bool B0>
-__global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : 1) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg) {
+__global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : (LEAN ? 1 : CHIP_SHADE_FULL_WAVES)) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg) {
   const uint32_t bounce = B0 ? 0u : bounce_arg;
 #if CHIP_SHADE_PRIO
   __builtin_amdgcn_s_setprio(CHIP_SHADE_PRIO);
