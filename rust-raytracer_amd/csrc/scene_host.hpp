@@ -512,8 +512,8 @@ struct HostScene {
           g.first = (uint32_t)F.gchild.size();
           g.count = (uint32_t)refs.size();
           F.gchild.insert(F.gchild.end(), refs.begin(), refs.end());
-          // The reference's Group tests every child (group.rs:44-54); the ordered traversal first asks the child's
-          // box, in f32 and rounded outward like the culling trees' boxes, whether the ray can reach it at all.
+          // each child's box, in f32 and rounded outward: what build_wnodes() files the child under when it opens the
+          // Group into a culling tree (host only)
           for (int k : n.kids) {
             float b[6];
             set_cull_box(b, H.nodes[k].box);
@@ -755,10 +755,10 @@ struct HostScene {
   // tie, and is what the literal traversal walks); for culling, the same member list is re-split by a binned
   // surface-area heuristic, which is free to separate a huge member (the r = 1000 ground sphere) from the
   // small ones instead of cutting the sorted list in half (bvh.rs:16-46).  A culling node stores the f32
-  // boxes of its two children: minima rounded down and maxima up, so each contains the reference's f64
-  // box; infinities (empty boxes, aabb.rs:41-47) become +-FLT_MAX so the device's multiply-add slab test
-  // never forms inf - inf.  The culling nodes of one hierarchy live in the table slots of that
-  // hierarchy's reference nodes (there are at least as many), root in the root's slot, top levels first.
+  // boxes of up to four children: minima rounded down and maxima up, so each contains the reference's f64
+  // box; infinities become +-FLT_MAX so the device's multiply-add slab test never forms inf - inf.  The
+  // culling nodes of one hierarchy live in the table slots of that hierarchy's reference nodes, root in
+  // the root's slot, top levels first, and in appended slots when those run out (see build_wnodes).
   struct SahLeaf {
     nref_t ref;
     Box6 box;
