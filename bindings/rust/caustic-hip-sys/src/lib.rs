@@ -178,6 +178,7 @@ extern "C" {
     pub fn chip_trace_rays(s: *mut chip_scene, seed: u64, n: usize, origin: *const f64, direction: *const f64, time: *const f64, out: *mut chip_hit) -> c_int;
     pub fn chip_camera_rays(s: *mut chip_scene, seed: u64, n: usize, xyss: *const u32, rays: *mut f64) -> c_int;
     pub fn chip_dump_tree(s: *mut chip_scene, kinds: *mut i32, ids: *mut i32, boxes: *mut f64, cap: usize) -> i64;
+    pub fn chip_check_culling_trees(s: *mut chip_scene) -> i64;
 }
 
 /// The last error message of this thread.

@@ -267,6 +267,12 @@ int chip_camera_rays(chip_scene* s, uint64_t seed, size_t n, const uint32_t* xys
  * nodes built internally), bbox as xmin,xmax,ymin,ymax,zmin,zmax.  Returns the record count,
  * which may exceed cap (then only cap records were written). */
 int64_t chip_dump_tree(chip_scene* s, int32_t* kinds, int32_t* ids, double* boxes, size_t cap);
+/* Consistency check of the library's own acceleration structure (no counterpart in the reference, needs no GPU):
+ * flattens the scene and verifies that the culling trees the ordered traversal walks reach exactly the primitives,
+ * media and instances that the reference's structure (bounding_volume_hierarchy.rs:16-46 hierarchies, Groups,
+ * instances) reaches, each once, that nested culling boxes contain one another, and that unused child slots cannot be
+ * hit.  Returns the number of primitives reached, < 0 with chip_last_error() set when a check fails. */
+int64_t chip_check_culling_trees(chip_scene* s);
 
 #ifdef __cplusplus
 }

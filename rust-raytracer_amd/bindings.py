@@ -198,6 +198,7 @@ class Backend:
             "resolve_device": (i, [p, p, C.c_size_t, p, p, p]),
             "scene_from_flat": (C.c_int64, [p, C.POINTER(FlatScene), pi32]),
             "commit_devices": (i, [p, pi32, i]),
+            "check_culling_trees": (C.c_int64, [p]),
             "render_frame_blocks": (i, [p, C.POINTER(RenderOpts), C.c_uint32, C.c_uint32, BLOCK_FN, p, C.POINTER(Stats)]),
             "write_png": (i, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]),
             "render_frame_multi": (i, [p, C.POINTER(RenderOpts), p, C.POINTER(C.c_uint8), C.POINTER(Stats)]),
@@ -541,6 +542,10 @@ class Scene:
         out = np.zeros((n, 7), dtype=np.float64)
         self._call("camera_rays", seed, n, _ptr(a, C.c_uint32), _ptr(out, C.c_double))
         return out
+
+    def check_culling_trees(self):
+        """Host-side consistency check of the GPU library's culling trees; returns the number of primitives they reach."""
+        return self.be.check(self.be.fn("check_culling_trees")(self.h))
 
     def dump_tree(self):
         """Preorder (kind, creation id, bbox) records of the world tree."""

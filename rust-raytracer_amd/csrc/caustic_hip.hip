@@ -1596,4 +1596,95 @@ int64_t chip_dump_tree(chip_scene* s, int32_t* kinds, int32_t* ids, double* boxe
   return (int64_t)count;
 }
 
+// Flattens the scene on the host (no device is touched) and checks the culling trees of the ordered traversal against
+// the reference-order structure they were derived from.
+int64_t chip_check_culling_trees(chip_scene* s) {
+  NEED_SCENE;
+  Flat F;
+  try {
+    s->host.flatten(F);
+  } catch (const std::exception& e) {
+    return fail(e.what());
+  }
+  // what a walk meets: primitives, media (their boundaries are not entered) and sphere-only Translates, as (kind, index)
+  auto is_unit = [&](nref_t r) {
+    const uint32_t k = NREF_KIND(r);
+    return k == NK_SPHERE || k == NK_QUAD || k == NK_DISC || k == NK_CONE || k == NK_MEDIUM ||
+           (k == NK_TRANSLATE && F.translates[NREF_INDEX(r)].only_sphere != NREF_NONE);
+  };
+  std::vector<nref_t> ref_units, ord_units, work;
+  // reference order: hierarchies by their two children, Groups by their child lists, instances by `child`
+  work.assign(1, F.root);
+  while (!work.empty()) {
+    const nref_t r = work.back();
+    work.pop_back();
+    if (r == NREF_NONE) continue;
+    const uint32_t k = NREF_KIND(r), i = NREF_INDEX(r);
+    if (is_unit(r)) { ref_units.push_back(r); continue; }
+    if (k == NK_BVH) {
+      if (i >= F.bvh.size()) return fail("reference node index out of range");
+      work.push_back(F.bvh[i].left);
+      if (F.bvh[i].right != F.bvh[i].left) work.push_back(F.bvh[i].right);  // a single member is held twice (bvh.rs:27-28)
+    } else if (k == NK_GROUP) {
+      for (uint32_t j = 0; j < F.groups[i].count; j++) work.push_back(F.gchild[F.groups[i].first + j]);
+    } else if (k == NK_TRANSLATE) work.push_back(F.translates[i].child);
+    else if (k == NK_ROTATE) work.push_back(F.rotates[i].child);
+    else if (k == NK_SCALE) work.push_back(F.scales[i].child);
+    else return fail("unexpected node kind in the reference-order structure");
+  }
+  // ordered traversal: culling nodes by their child words, instances by `ord_child` from the innermost instance of
+  // their run (enter_xform); it must meet no Group that holds anything
+  size_t n_nodes = 0;
+  work.assign(1, F.ord_root);
+  while (!work.empty()) {
+    const nref_t r = work.back();
+    work.pop_back();
+    if (r == NREF_NONE) continue;
+    const uint32_t k = NREF_KIND(r), i = NREF_INDEX(r);
+    if (is_unit(r)) { ord_units.push_back(r); continue; }
+    if (k == NK_BVH) {
+      if (i >= F.n_wide) return fail("a culling node in use lies outside the leading part of the table");
+      n_nodes++;
+      const DWNode& w = F.wnodes[i];
+      for (int c = 0; c < 4; c++) {
+        if (w.child[c] == NREF_NONE) {
+          if (!(w.lo_x[c] > w.hi_x[c] && w.lo_y[c] > w.hi_y[c] && w.lo_z[c] > w.hi_z[c])) return fail("an unused child slot does not hold an inverted box");
+          continue;
+        }
+        if (NREF_KIND(w.child[c]) == NK_BVH) {  // the child node's own children lie inside the box this node holds for it
+          if (NREF_INDEX(w.child[c]) >= F.wnodes.size()) return fail("culling node index out of range");
+          const DWNode& v = F.wnodes[NREF_INDEX(w.child[c])];
+          for (int d = 0; d < 4; d++) {
+            if (v.child[d] == NREF_NONE) continue;
+            if (v.lo_x[d] < w.lo_x[c] || v.hi_x[d] > w.hi_x[c] || v.lo_y[d] < w.lo_y[c] || v.hi_y[d] > w.hi_y[c] || v.lo_z[d] < w.lo_z[c] ||
+                v.hi_z[d] > w.hi_z[c])
+              return fail("a culling node's box does not contain its grandchildren's");
+          }
+        }
+        work.push_back(w.child[c]);
+      }
+    } else if (k == NK_GROUP) {
+      std::vector<nref_t> g(1, r);  // only Groups without content may be left
+      while (!g.empty()) {
+        const nref_t q = g.back();
+        g.pop_back();
+        if (NREF_KIND(q) != NK_GROUP) return fail("the ordered traversal would meet a Group that holds something");
+        for (uint32_t j = 0; j < F.groups[NREF_INDEX(q)].count; j++) g.push_back(F.gchild[F.groups[NREF_INDEX(q)].first + j]);
+      }
+    } else if (k == NK_TRANSLATE || k == NK_ROTATE || k == NK_SCALE) {
+      const nref_t x = k == NK_TRANSLATE ? F.translates[i].enter_xform : (k == NK_ROTATE ? F.rotates[i].enter_xform : F.scales[i].enter_xform);
+      const uint32_t xk = NREF_KIND(x), xi = NREF_INDEX(x);
+      work.push_back(xk == NK_TRANSLATE ? F.translates[xi].ord_child : (xk == NK_ROTATE ? F.rotates[xi].ord_child : F.scales[xi].ord_child));
+    } else {
+      return fail("unexpected node kind in the culling trees");
+    }
+  }
+  std::sort(ref_units.begin(), ref_units.end());
+  std::sort(ord_units.begin(), ord_units.end());
+  if (std::adjacent_find(ord_units.begin(), ord_units.end()) != ord_units.end()) return fail("the culling trees reach a primitive twice");
+  if (ref_units != ord_units) return fail("the culling trees do not reach the primitives the reference-order structure reaches");
+  (void)n_nodes;
+  return (int64_t)ord_units.size();
+}
+
 }  // extern "C"
