@@ -375,8 +375,10 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
   p.cache = !uncached && !s->flat.bvh.empty() && !(e && *e == '1');
   if (p.cache) {
     p.block = (uint32_t)extend_block(feat, true);
-    const bool ordered = true;  // an entry distance is kept beside every stack value
-    p.cd.stack_entries = ordered ? 8 : 12;
+    // (value, entry distance) pairs per lane kept in LDS; the rest of a deep descent goes to the spill slab.  Deep
+    // trees read from memory (instanced spheres) gain more from two further entries than from the 140 nodes of
+    // cache they cost; the sphere scenes' trees are shallow
+    p.cd.stack_entries = (feat & TF_NO_QUADROT) ? 10 : 8;
     if (const char* es = getenv("CHIP_LDS_STACK")) { int v = atoi(es); if (v >= 2 && v <= 16) p.cd.stack_entries = (uint32_t)v; }
     const uint32_t stack_bytes = p.cd.stack_entries * 8 * p.block;
     const uint32_t node_bytes = 16 * CHIP_WNODE_U4, sphere_bytes = 64;
