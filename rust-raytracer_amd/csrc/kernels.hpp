@@ -425,18 +425,15 @@ __device__ inline void ray_set_cull(TravRay& r) {
   const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
 #pragma unroll
   for (int a = 0; a < 3; a++) {
+    // The near plane is the low one for d > 0 and the high one for d < 0; either way its distance (plane - o) / d
+    // shrinks when |1/d| does, and the far plane's grows when |1/d| does, so the two multipliers do not depend on
+    // the sign: only which plane they are applied to does (far16).
     const float invf = __frcp_rn((float)d[a]);
-    const bool pos = invf > 0.0f;
-    const float s = pos ? CHIP_CULL_DELTA : -CHIP_CULL_DELTA;
-    const float ml = invf * (1.0f - s), mh = invf * (1.0f + s);  // multipliers of the low / the high plane
-    const double cl = -(o[a] * (double)ml), ch = -(o[a] * (double)mh);
-    const float c_low = pos ? f32_below(cl) : f32_above(cl);  // the low plane is the near one iff d > 0
-    const float c_high = pos ? f32_above(ch) : f32_below(ch);
-    r.m_n[a] = pos ? ml : mh;
-    r.c_n[a] = pos ? c_low : c_high;
-    r.m_f[a] = pos ? mh : ml;
-    r.c_f[a] = pos ? c_high : c_low;
-    r.far16[a] = pos ? 0u : 16u;
+    r.m_n[a] = invf * (1.0f - CHIP_CULL_DELTA);
+    r.m_f[a] = invf * (1.0f + CHIP_CULL_DELTA);
+    r.c_n[a] = f32_below(-(o[a] * (double)r.m_n[a]));
+    r.c_f[a] = f32_above(-(o[a] * (double)r.m_f[a]));
+    r.far16[a] = invf > 0.0f ? 0u : 16u;
   }
 }
 
