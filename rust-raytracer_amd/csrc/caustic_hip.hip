@@ -1645,9 +1645,13 @@ int64_t chip_check_culling_trees(chip_scene* s) {
     const uint32_t k = NREF_KIND(r), i = NREF_INDEX(r);
     if (is_unit(r)) { ord_units.push_back(r); continue; }
     if (k == NK_BVH) {
-      if (i >= F.n_wide) return fail("a culling node in use lies outside the leading part of the table");
+      if (i >= F.wnodes.size()) return fail("culling node index out of range");
       n_nodes++;
       const DWNode& w = F.wnodes[i];
+      // nodes with children lead the table (they are what the traversal kernel copies into LDS); the root of a
+      // hierarchy that holds nothing may lie behind them
+      if (i >= F.n_wide && (w.child[0] != NREF_NONE || w.child[1] != NREF_NONE || w.child[2] != NREF_NONE || w.child[3] != NREF_NONE))
+        return fail("a culling node with children lies outside the leading part of the table");
       for (int c = 0; c < 4; c++) {
         if (w.child[c] == NREF_NONE) {
           if (!(w.lo_x[c] > w.hi_x[c] && w.lo_y[c] > w.hi_y[c] && w.lo_z[c] > w.hi_z[c])) return fail("an unused child slot does not hold an inverted box");
