@@ -537,6 +537,11 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
       set_magic(B.npix_magic, npix);
       set_magic(B.rect_w_magic, pl.rw);
       set_magic(B.sqrt_spp_magic, cam.sqrt_spp);
+      {
+        static const bool linear = [] { const char* e = getenv("CHIP_LINEAR_PIXELS"); return e && *e == '1'; }();
+        B.tiles_per_row = (!linear && pl.rw % 8u == 0 && bh % 8u == 0) ? pl.rw / 8u : 0u;
+        set_magic(B.tiles_magic, B.tiles_per_row ? B.tiles_per_row : 1u);
+      }
       B.n_strata = std::min(spb, pl.s_count - sb0);
       B.stratum_first = pl.s_first + sb0 * pl.s_stride;
       B.stratum_stride = pl.s_stride;

@@ -98,6 +98,10 @@ struct BatchDesc {
   uint32_t stratum_first, stratum_stride;     // global stratum of batch-local sb: first + sb*stride
   uint32_t n_paths;                           // npix * n_strata
   uint32_t npix_magic[2], rect_w_magic[2], sqrt_spp_magic[2];  // ceil(2^64 / divisor), low and high word (0, 0 for a divisor of 1)
+  // Order of a stratum's paths over the rectangle: 8 x 8 pixel tiles, tile after tile (tiles_per_row = rect_w / 8), when
+  // both sides of the rectangle are multiples of 8; row after row (tiles_per_row = 0) otherwise.  A wave's 64 camera
+  // rays then cover a compact patch of the image, and so do the paths that are still alive later.
+  uint32_t tiles_per_row, tiles_magic[2];
   uint32_t seed_lo, seed_hi;
   uint32_t reference_order;                   // trace every ray in the reference's own visiting order
 };
@@ -1469,12 +1473,25 @@ __host__ __device__ inline uint32_t magic_div(uint32_t n, const uint32_t c[2]) {
   const unsigned long long lo = (unsigned long long)c[0] * n, hi = (unsigned long long)c[1] * n;
   return (uint32_t)((hi + (lo >> 32)) >> 32);
 }
+// Position inside the batch's rectangle of the p-th path of a stratum (see BatchDesc::tiles_per_row).
+__device__ inline void rect_pixel(const BatchDesc& B, uint32_t p, uint32_t& xl, uint32_t& yl) {
+  if (B.tiles_per_row) {
+    const uint32_t t = p >> 6, i = p & 63u;
+    const uint32_t trow = magic_div(t, B.tiles_magic), tcol = t - trow * B.tiles_per_row;
+    xl = tcol * 8u + (i & 7u);
+    yl = trow * 8u + (i >> 3);
+  } else {
+    yl = magic_div(p, B.rect_w_magic);
+    xl = p - yl * B.rect_w;
+  }
+}
 __device__ inline void slot_to_path(const BatchDesc& B, const DCamera& cam, uint32_t slot, uint32_t& x, uint32_t& y, uint32_t& pixel,
                                     uint32_t& stratum) {
   const uint32_t sb = magic_div(slot, B.npix_magic), p = slot - sb * B.npix;
-  const uint32_t row = magic_div(p, B.rect_w_magic);
-  y = B.rect_y0 + row;
-  x = B.rect_x0 + (p - row * B.rect_w);
+  uint32_t xl, yl;
+  rect_pixel(B, p, xl, yl);
+  y = B.rect_y0 + yl;
+  x = B.rect_x0 + xl;
   pixel = y * cam.image_width + x;
   stratum = B.stratum_first + sb * B.stratum_stride;
 }
@@ -1989,16 +2006,19 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : (LEAN ? 1 : C
 __global__ void __launch_bounds__(CHIP_BLOCK) k_accumulate(PathPool P, BatchDesc B, float* sum_rgb) {
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < B.npix; p += gridDim.x * blockDim.x) {
     // the running sums take one sample after the other, so the result does not depend on where the batches were cut
-    float r = sum_rgb[(size_t)p * 3 + 0], g = sum_rgb[(size_t)p * 3 + 1], b = sum_rgb[(size_t)p * 3 + 2];
+    uint32_t xl, yl;
+    rect_pixel(B, p, xl, yl);
+    const size_t q = (size_t)yl * B.rect_w + xl;  // the pixel's place in the band's row-major sums
+    float r = sum_rgb[q * 3 + 0], g = sum_rgb[q * 3 + 1], b = sum_rgb[q * 3 + 2];
     for (uint32_t sb = 0; sb < B.n_strata; sb++) {
       const float4 v = P.sample[(size_t)sb * B.npix + p];
       r += v.x;
       g += v.y;
       b += v.z;
     }
-    sum_rgb[(size_t)p * 3 + 0] = r;
-    sum_rgb[(size_t)p * 3 + 1] = g;
-    sum_rgb[(size_t)p * 3 + 2] = b;
+    sum_rgb[q * 3 + 0] = r;
+    sum_rgb[q * 3 + 1] = g;
+    sum_rgb[q * 3 + 2] = b;
   }
 }
 
