@@ -487,6 +487,9 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   for (const DTexture& t : s->host.textures) solid_only = solid_only && t.kind == TK_SOLID;
   const bool lean = feat == 0 && solid_only;
   // the same under Translate / Rotate instances (instanced spheres, nothing else to intersect)
+  // solid colours and checkers only: the full shade kernel without its image / noise texture code
+  bool plain_textures = true;
+  for (const DTexture& t : s->host.textures) plain_textures = plain_textures && (t.kind == TK_SOLID || t.kind == TK_CHECKER);
   const bool lean_xform = solid_only && (feat & ~TF_NO_QUADROT) == (TF_QUADS | TF_XFORM) && s->flat.quads.empty() && s->flat.media.empty();
 
   // pools: two when the render is large enough to be worth splitting
@@ -651,6 +654,14 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
           if (exact_shading) CHIP_SHADE(false, true, true); else CHIP_SHADE(true, true, true);
         } else if (ext) {
           if (exact_shading) CHIP_SHADE(false, false, true); else CHIP_SHADE(true, false, true);
+        } else if (plain_textures) {
+          if (bounce == 0) {
+            if (exact_shading) hipLaunchKernelGGL((k_shade_tiles<false, false, false, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
+            else hipLaunchKernelGGL((k_shade_tiles<true, false, false, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
+          } else {
+            if (exact_shading) hipLaunchKernelGGL((k_shade_tiles<false, false, false, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
+            else hipLaunchKernelGGL((k_shade_tiles<true, false, false, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
+          }
         } else {
           if (exact_shading) CHIP_SHADE(false, false, false); else CHIP_SHADE(true, false, false);
         }

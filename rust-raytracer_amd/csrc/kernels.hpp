@@ -1151,9 +1151,13 @@ __device__ inline double perlin_turbulence(const DPerlin& P, V3 pt, uint32_t dep
   }
   return fabs(acc);
 }
+// PLAIN: the scene's textures are solid colours and checkers only (told by the host), so the image and noise code, with
+// the registers its table look-ups and sine need, is left out of the kernel.
+template <bool PLAIN>
 __device__ inline V3 tex_value(const DScene& S, int tex, double u, double v, V3 pt) {
   for (int guard = 0; guard < 64; guard++) {
     const DTexture& T = S.textures[tex];
+    if (PLAIN && T.kind != TK_SOLID && T.kind != TK_CHECKER) return mk(0, 0, 0);  // (not reached: the host checked)
     switch (T.kind) {
       case TK_SOLID: return mk(T.p[0], T.p[1], T.p[2]);  // solid_color.rs:14-17
       case TK_CHECKER: {                                  // checker_texture.rs:22-35
@@ -1164,6 +1168,7 @@ __device__ inline V3 tex_value(const DScene& S, int tex, double u, double v, V3 
         break;
       }
       case TK_IMAGE: {  // image_texture.rs:16-29, image.rs:58-66
+        if (PLAIN) return mk(0, 0, 0);
         double uc = rclamp(u, 0.0, 1.0);
         double vc = 1.0 - rclamp(v, 0.0, 1.0);
         uint32_t i = (uint32_t)(uc * (double)T.a);
@@ -1173,10 +1178,12 @@ __device__ inline V3 tex_value(const DScene& S, int tex, double u, double v, V3 
         return mk((double)p[0] / 255.0, (double)p[1] / 255.0, (double)p[2] / 255.0);
       }
       case TK_NOISE: {  // perlin_noise.rs:18-22
+        if (PLAIN) return mk(0, 0, 0);
         double s = 0.5 * (1.0 + perlin_noise(S.perlins[T.a], T.p[0] * pt));
         return mk(s, s, s);
       }
       default: {  // TK_TURBULENCE, perlin_turbulence.rs:20-27
+        if (PLAIN) return mk(0, 0, 0);
         double s = 0.5 * (1.0 + sin(T.p[0] * pt.z + 10.0 * perlin_turbulence(S.perlins[T.a], pt, T.b)));
         return mk(s, s, s);
       }
@@ -1733,7 +1740,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
 // LEAN is the variant for scenes made only of spheres with solid-colour textures and no lights (no
 // transforms, quads, media, image / noise / checker textures or light sampling to carry in registers);
 // LEAN with EXT is the same for spheres under Translate / Rotate instances.
-template <uint32_t KIND, bool FAST, bool LEAN, bool EXT>
+template <uint32_t KIND, bool FAST, bool LEAN, bool EXT, bool PLAIN>
 __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t bounce, uint32_t slot, const PathHit& ph, V3 ro, V3 rd,
                                  double rtime, float (&xw)[3], float& klo_out, float& khi_out, V3& next_o, V3& next_d) {
   bool cont = false;
@@ -1743,13 +1750,13 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
   const DMaterial& M = S.materials[MATK_ID(ph.info)];
   const bool has_lights = !LEAN && S.has_lights;
   HitOut hrec;
-  reconstruct<LEAN ? (EXT ? TF_XFORM : 0u) : (TF_QUADS | TF_XFORM | TF_MEDIA | (EXT ? TF_EXT : 0u)), FAST>(S, leaf, ph.t, ro, rd, rtime, hrec, !LEAN && (M.flags & MF_NEEDS_UV) != 0);
+  reconstruct<LEAN ? (EXT ? TF_XFORM : 0u) : (TF_QUADS | TF_XFORM | TF_MEDIA | (EXT ? TF_EXT : 0u)), FAST>(S, leaf, ph.t, ro, rd, rtime, hrec, !LEAN && !PLAIN && (M.flags & MF_NEEDS_UV) != 0);
   const bool front = hrec.front;
   const V3 pt = hrec.pt;
   if (KIND == MK_DIFFUSE_LIGHT) {
     // diffuse_light.rs:28-43: no scatter; emits on the front face only
     if (front) {
-      V3 e = LEAN ? ld3(M.p) : tex_value(S, M.tex, hrec.u, hrec.v, pt);
+      V3 e = LEAN ? ld3(M.p) : tex_value<PLAIN>(S, M.tex, hrec.u, hrec.v, pt);
       xw[0] = (float)e.x; xw[1] = (float)e.y; xw[2] = (float)e.z;
     }
   } else if (KIND == MK_EMPTY) {
@@ -1788,7 +1795,7 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
       w[0] = 1.f; w[1] = 1.f; w[2] = 1.f;
     } else {
       // Lambertian (lambertian.rs:29-49) / Isotropic (isotropic.rs:29-44): PDF branch, camera.rs:278-305
-      V3 atten = LEAN ? ld3(M.p) : tex_value(S, M.tex, hrec.u, hrec.v, pt);  // solid_color.rs:14-17 (colour copied into the material)
+      V3 atten = LEAN ? ld3(M.p) : tex_value<PLAIN>(S, M.tex, hrec.u, hrec.v, pt);  // solid_color.rs:14-17 (colour copied into the material)
       bool use_light = false;
       if (has_lights) use_light = rng.next() < 0.5;  // mixture.rs:26-32
       if (FAST) {
@@ -1874,7 +1881,7 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
 #define CHIP_SHADE_TILE 1024
 // B0: the instantiation for bounce 0, whose entries are the batch's paths in order with their camera rays
 // recomputed and the identity as radiance map; kept apart so that neither variant pays registers for the other.
-template <bool FAST, bool LEAN, bool EXT, bool B0>
+template <bool FAST, bool LEAN, bool EXT, bool B0, bool PLAIN = false>
 __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : (LEAN ? 1 : CHIP_SHADE_FULL_WAVES)) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg) {
   const uint32_t bounce = B0 ? 0u : bounce_arg;
 #if CHIP_SHADE_PRIO
@@ -1951,7 +1958,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : (LEAN ? 1 : C
       }                                                                                                          \
       float xw[3] = {0.f, 0.f, 0.f}, klo = 0.f, khi = 0.f;                                                       \
       bool cont = false;                                                                                         \
-      if (valid) cont = shade_hit<KIND, FAST, LEAN, EXT>(S, B, bounce, id, ph, ro, rd, rtime, xw, klo, khi, no, nd); \
+      if (valid) cont = shade_hit<KIND, FAST, LEAN, EXT, PLAIN>(S, B, bounce, id, ph, ro, rd, rtime, xw, klo, khi, no, nd); \
       Affine f;  /* loaded after the material code, which is where the registers are scarce */                  \
       quad_load_map<B0>(P, entry, lane, bounce, stage, f, id);                                                   \
       if (valid) {                                                                                               \
