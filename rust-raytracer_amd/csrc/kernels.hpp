@@ -37,9 +37,13 @@
 #ifndef CHIP_DESCENT_DEN_MEDIA
 #define CHIP_DESCENT_DEN_MEDIA 8u
 #endif
-// Waves per SIMD the full shade kernel (every material, texture and light kind) is register-allocated for.
+// Waves per SIMD the full shade kernel (every material, texture and light kind) is register-allocated for, and its
+// form without image / noise textures (130 VGPRs on its own: 4 waves cost it a handful of spills at bounce 0).
 #ifndef CHIP_SHADE_FULL_WAVES
 #define CHIP_SHADE_FULL_WAVES 1
+#endif
+#ifndef CHIP_SHADE_PLAIN_WAVES
+#define CHIP_SHADE_PLAIN_WAVES 4
 #endif
 #ifndef CHIP_REFILL_THRESH
 #define CHIP_REFILL_THRESH 48  // a traversing wave refills its idle lanes once fewer than this many are busy
@@ -1882,7 +1886,7 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
 // B0: the instantiation for bounce 0, whose entries are the batch's paths in order with their camera rays
 // recomputed and the identity as radiance map; kept apart so that neither variant pays registers for the other.
 template <bool FAST, bool LEAN, bool EXT, bool B0, bool PLAIN = false>
-__global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : (LEAN ? 1 : CHIP_SHADE_FULL_WAVES)) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg) {
+__global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : (LEAN ? 1 : (PLAIN ? CHIP_SHADE_PLAIN_WAVES : CHIP_SHADE_FULL_WAVES))) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg) {
   const uint32_t bounce = B0 ? 0u : bounce_arg;
 #if CHIP_SHADE_PRIO
   __builtin_amdgcn_s_setprio(CHIP_SHADE_PRIO);
