@@ -643,28 +643,31 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
       n_trace_launches++;
       {
         const bool ext = (feat & TF_EXT) != 0;
-#define CHIP_SHADE(FAST, LEAN, EXT)                                                                                            \
+#define CHIP_SHADE(FAST, LEAN, EXT, PASS)                                                                                          \
   do {                                                                                                                         \
-    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce); \
-    else hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT, false>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce); \
+    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
+    else hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT, false>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
+  } while (0)
+        // the full kernel's form without image / noise texture code: everything (SHADE_ALL) when the scene has no such
+        // texture, else everything but the hits on materials that have one, which a second launch of the full kernel takes
+#define CHIP_SHADE_PLAIN(FAST, PASS)                                                                                           \
+  do {                                                                                                                         \
+    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, false, false, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
+    else hipLaunchKernelGGL((k_shade_tiles<FAST, false, false, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
   } while (0)
         if (lean) {
-          if (exact_shading) CHIP_SHADE(false, true, false); else CHIP_SHADE(true, true, false);
+          if (exact_shading) CHIP_SHADE(false, true, false, SHADE_ALL); else CHIP_SHADE(true, true, false, SHADE_ALL);
         } else if (lean_xform) {
-          if (exact_shading) CHIP_SHADE(false, true, true); else CHIP_SHADE(true, true, true);
+          if (exact_shading) CHIP_SHADE(false, true, true, SHADE_ALL); else CHIP_SHADE(true, true, true, SHADE_ALL);
         } else if (ext) {
-          if (exact_shading) CHIP_SHADE(false, false, true); else CHIP_SHADE(true, false, true);
+          if (exact_shading) CHIP_SHADE(false, false, true, SHADE_ALL); else CHIP_SHADE(true, false, true, SHADE_ALL);
         } else if (plain_textures) {
-          if (bounce == 0) {
-            if (exact_shading) hipLaunchKernelGGL((k_shade_tiles<false, false, false, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
-            else hipLaunchKernelGGL((k_shade_tiles<true, false, false, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
-          } else {
-            if (exact_shading) hipLaunchKernelGGL((k_shade_tiles<false, false, false, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
-            else hipLaunchKernelGGL((k_shade_tiles<true, false, false, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce);
-          }
+          if (exact_shading) CHIP_SHADE_PLAIN(false, SHADE_ALL); else CHIP_SHADE_PLAIN(true, SHADE_ALL);
         } else {
-          if (exact_shading) CHIP_SHADE(false, false, false); else CHIP_SHADE(true, false, false);
+          if (exact_shading) CHIP_SHADE_PLAIN(false, SHADE_PLAIN_ONLY); else CHIP_SHADE_PLAIN(true, SHADE_PLAIN_ONLY);
+          if (exact_shading) CHIP_SHADE(false, false, false, SHADE_RICH_ONLY); else CHIP_SHADE(true, false, false, SHADE_RICH_ONLY);
         }
+#undef CHIP_SHADE_PLAIN
 #undef CHIP_SHADE
       }
       if (time_kernels && stamp()) return -1;
@@ -1187,8 +1190,18 @@ int chip_commit(chip_scene* s) {
       uv[t] = r ? 1 : 0;
       return r;
     };
+    std::vector<int> rich_of(T.size(), -1);
+    std::function<bool(int, int)> rich = [&](int t, int depth) -> bool {
+      if (t < 0 || (size_t)t >= T.size() || depth > 64) return true;
+      if (rich_of[t] >= 0) return rich_of[t] != 0;
+      bool r = (T[t].kind != TK_SOLID && T[t].kind != TK_CHECKER) ||
+               (T[t].kind == TK_CHECKER && (rich((int)T[t].a, depth + 1) || rich((int)T[t].b, depth + 1)));
+      rich_of[t] = r ? 1 : 0;
+      return r;
+    };
     for (DMaterial& m : s->host.materials) {
       m.flags = (m.tex >= 0 && needs(m.tex, 0)) ? MF_NEEDS_UV : 0u;
+      if (m.tex >= 0 && rich(m.tex, 0)) m.flags |= MF_RICH_TEX;
       // a solid-colour texture's value rides in the material record (read by the lean shade kernels)
       if ((m.kind == MK_LAMBERTIAN || m.kind == MK_DIFFUSE_LIGHT || m.kind == MK_ISOTROPIC) && m.tex >= 0 && (size_t)m.tex < T.size() &&
           T[m.tex].kind == TK_SOLID)

@@ -143,7 +143,10 @@ struct alignas(8) DMedium {
 };
 
 enum : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_DIFFUSE_LIGHT = 3, MK_ISOTROPIC = 4, MK_EMPTY = 5, MK_COUNT = 6 };
-enum : uint32_t { MF_NEEDS_UV = 1 };  // the material's texture tree contains an image texture (reads u, v)
+enum : uint32_t {
+  MF_NEEDS_UV = 1,  // the material's texture tree contains an image texture (reads u, v)
+  MF_RICH_TEX = 2,  // ... an image, noise or turbulence texture: shaded by the kernel that carries that code
+};
 struct alignas(8) DMaterial {
   uint32_t kind;
   int32_t tex;  // Lambertian / DiffuseLight / Isotropic texture id

@@ -1885,8 +1885,10 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
 #define CHIP_SHADE_TILE 1024
 // B0: the instantiation for bounce 0, whose entries are the batch's paths in order with their camera rays
 // recomputed and the identity as radiance map; kept apart so that neither variant pays registers for the other.
+// `pass`: which entries of the bounce this launch shades.
+enum : uint32_t { SHADE_ALL = 0, SHADE_PLAIN_ONLY = 1, SHADE_RICH_ONLY = 2 };
 template <bool FAST, bool LEAN, bool EXT, bool B0, bool PLAIN = false>
-__global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : (LEAN ? 1 : (PLAIN ? CHIP_SHADE_PLAIN_WAVES : CHIP_SHADE_FULL_WAVES))) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg) {
+__global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : (LEAN ? 1 : (PLAIN ? CHIP_SHADE_PLAIN_WAVES : CHIP_SHADE_FULL_WAVES))) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg, uint32_t pass) {
   const uint32_t bounce = B0 ? 0u : bounce_arg;
 #if CHIP_SHADE_PRIO
   __builtin_amdgcn_s_setprio(CHIP_SHADE_PRIO);
@@ -1898,7 +1900,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : (LEAN ? 1 : (
   uint32_t* ctr_next = P.counters + (size_t)(bounce + 1) * CHIP_CTR_STRIDE;
   const uint32_t n_live = ctr[0];
   const bool last_bounce = bounce + 1 >= S.cam.max_depth;
-  constexpr uint32_t NB = MK_COUNT + 2;        // material kinds, misses, empty entries
+  constexpr uint32_t NB = MK_COUNT + 3;        // material kinds, misses, empty entries, entries left to the other pass
   __shared__ uint16_t s_order[CHIP_SHADE_TILE];  // tile-local entry numbers, sorted by bin
   __shared__ uint16_t s_rank[CHIP_SHADE_TILE];
   __shared__ uint8_t s_kind[CHIP_SHADE_TILE];
@@ -1917,7 +1919,13 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : (LEAN ? 1 : (
     const uint32_t tile_n = min(tile, n_live - tile0);
     for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
       const uint2 hw = *reinterpret_cast<const uint2*>(&P.hit[tile0 + k].node);
-      const uint32_t kind = hw.x == NREF_NONE ? MK_COUNT : (hw.x == NREF_DEAD ? MK_COUNT + 1 : MATK_KIND(hw.y));
+      uint32_t kind = hw.x == NREF_NONE ? MK_COUNT : (hw.x == NREF_DEAD ? MK_COUNT + 1 : MATK_KIND(hw.y));
+      if (pass != SHADE_ALL) {
+        // two launches share the bounce: hits on materials with an image / noise texture go to the second one (the
+        // full kernel), everything else, misses included, to the first (the kernel without that code)
+        const bool rich = kind < MK_COUNT && (S.materials[MATK_ID(hw.y)].flags & MF_RICH_TEX) != 0;
+        if (rich != (pass == SHADE_RICH_ONLY)) kind = MK_COUNT + 2;
+      }
       s_kind[k] = (uint8_t)kind;
       s_rank[k] = (uint16_t)atomicAdd(&s_cnt[kind], 1u);
     }
