@@ -37,8 +37,13 @@
 #ifndef CHIP_DESCENT_DEN_MEDIA
 #define CHIP_DESCENT_DEN_MEDIA 8u
 #endif
-// Waves per SIMD the full shade kernel (every material, texture and light kind) is register-allocated for, and its
-// form without image / noise textures (130 VGPRs on its own: 4 waves cost it a handful of spills at bounce 0).
+// Waves per SIMD the shade kernels are register-allocated for.  Lean kernels (spheres, solid colours, no lights): 4
+// (128 VGPRs, no spills; one such wave per SIMD still fits beside the sphere traversal's four 96-VGPR waves; 5 and 6
+// spill and measure 1-3 % slower).  Full kernel (every material, texture and light kind): whatever it needs (about
+// 250).  Its form without image / noise textures needs 130-141 on its own: 4 waves cost it a few spills at bounce 0.
+#ifndef CHIP_SHADE_LEAN_WAVES
+#define CHIP_SHADE_LEAN_WAVES 4
+#endif
 #ifndef CHIP_SHADE_FULL_WAVES
 #define CHIP_SHADE_FULL_WAVES 1
 #endif
@@ -1888,7 +1893,7 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
 // `pass`: which entries of the bounce this launch shades.
 enum : uint32_t { SHADE_ALL = 0, SHADE_PLAIN_ONLY = 1, SHADE_RICH_ONLY = 2 };
 template <bool FAST, bool LEAN, bool EXT, bool B0, bool PLAIN = false>
-__global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? 5 : (LEAN ? 1 : (PLAIN ? CHIP_SHADE_PLAIN_WAVES : CHIP_SHADE_FULL_WAVES))) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg, uint32_t pass) {
+__global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_WAVES : (LEAN ? 1 : (PLAIN ? CHIP_SHADE_PLAIN_WAVES : CHIP_SHADE_FULL_WAVES))) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg, uint32_t pass) {
   const uint32_t bounce = B0 ? 0u : bounce_arg;
 #if CHIP_SHADE_PRIO
   __builtin_amdgcn_s_setprio(CHIP_SHADE_PRIO);
