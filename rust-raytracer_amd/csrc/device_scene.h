@@ -64,6 +64,12 @@ struct alignas(128) DSphere {
   nref_t xform;  // innermost Translate/Rotate ancestor, or NREF_NONE
   int32_t leaf_id;
   uint32_t seq;  // position of this primitive in the reference's depth-first visiting order
+  // When all that stands between the sphere and the world is one Translate (xform, with no transform above it): that
+  // Translate's offset, so that rebuilding the hit record reads this record only (instanced-sphere scenes hold a
+  // million of each, scattered over memory).
+  double xoff[3];
+  uint32_t xoff_only;  // xoff is valid
+  uint32_t pad;
 };
 
 struct alignas(16) DQuad {

@@ -1046,7 +1046,11 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
   uint32_t kind = NREF_KIND(leaf), idx = NREF_INDEX(leaf);
   nref_t x = NREF_NONE;
   V3 o = wo, d = wd;
-  if (F & TF_XFORM) {
+  // a sphere below a single Translate: translate.rs:26-38 from the copy of the offset in the sphere's own record
+  const bool lone_translate = (F & TF_XFORM) && kind == NK_SPHERE && S.spheres[idx].xoff_only != 0u;
+  if (lone_translate) {
+    o = wo - ld3(S.spheres[idx].xoff);
+  } else if (F & TF_XFORM) {
     if (kind == NK_SPHERE) x = S.spheres[idx].xform;
     else if (kind == NK_QUAD) x = S.quads[idx].xform;
     else if ((F & TF_EXT) && kind == NK_DISC) x = S.discs[idx].xform;
@@ -1110,7 +1114,9 @@ __device__ inline void reconstruct(const DScene& S, nref_t leaf, double t, V3 wo
     h.mat = MATK_ID(m.mat);
     h.leaf_id = m.leaf_id;
   }
-  if (F & TF_XFORM) {
+  if (lone_translate) {
+    h.pt = h.pt + ld3(S.spheres[idx].xoff);
+  } else if (F & TF_XFORM) {
     uint32_t first, n;
     xform_chain<(F & TF_EXT) != 0>(S, x, first, n);
     for (uint32_t i = n; i > 0; i--) {

@@ -437,6 +437,10 @@ struct HostScene {
       s.xform = xform;
       s.leaf_id = leaf_id;
       s.seq = seq++;
+      if (xform != NREF_NONE && NREF_KIND(xform) == NK_TRANSLATE && F.translates[NREF_INDEX(xform)].chain_len == 1) {
+        for (int i = 0; i < 3; i++) s.xoff[i] = F.translates[NREF_INDEX(xform)].off[i];
+        s.xoff_only = 1;
+      }
       F.spheres.push_back(s);
       return NREF(NK_SPHERE, F.spheres.size() - 1);
     }
