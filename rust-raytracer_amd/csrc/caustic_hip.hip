@@ -410,7 +410,15 @@ static int launch_extend_b(const DeviceState& D, const PathPool& P, const Extend
   uint32_t blocks = (n_live_upper + p.block - 1) / p.block;
   uint32_t max_blocks = CACHE ? (uint32_t)D.n_cus : kMaxGridBlocksDef;
   blocks = std::max(1u, std::min(blocks, max_blocks));
-  hipLaunchKernelGGL((k_extend<F, CACHE, ORD, B0>), dim3(blocks), dim3(p.block), p.lds_bytes, st, D.dscene, P, B, bounce, p.cd, lit_pass);
+  // A literal pass that is expected to find its queue empty is one wave: on a device full of the other batch's
+  // kernels a single wave finds a free slot sooner than a block of four, and it drains a queue of any length anyway.
+  uint32_t threads = p.block;
+  uint32_t lds_bytes = p.lds_bytes;
+  if (!CACHE && lit_pass && n_live_upper <= 1u) {
+    threads = 64u;
+    lds_bytes = p.cd.stack_entries * 8u * threads;
+  }
+  hipLaunchKernelGGL((k_extend<F, CACHE, ORD, B0>), dim3(blocks), dim3(threads), lds_bytes, st, D.dscene, P, B, bounce, p.cd, lit_pass);
   return 0;
 }
 template <uint32_t F, bool CACHE, bool ORD>
