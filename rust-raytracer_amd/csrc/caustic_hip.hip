@@ -450,7 +450,11 @@ static int launch_extend(const chip_scene* s, const DeviceState& D, const PathPo
   // the launch shape (threads per block, LDS split) must be planned for the instantiation that runs
   feat = extend_variant(feat);
   const ExtendPlan lit = plan_extend(s, feat, true);
-  const ExtendPlan p = plan_extend(s, feat, false);
+  // A short queue (the late bounces) is not worth a CU-filling block and its copy of the scene tables: it runs the
+  // plain 256-thread form, whose blocks also find room sooner beside the other batch's kernels (+2 % on the sphere
+  // and Cornell scenes).  Not for instanced spheres: their deep trees want the cached top levels even then.
+  static const uint32_t small_queue = [] { const char* e = getenv("CHIP_SMALL_QUEUE"); return e && *e ? (uint32_t)atol(e) : 16384u; }();
+  const ExtendPlan p = plan_extend(s, feat, !(feat & TF_NO_QUADROT) && n_live_upper < small_queue);
   const uint32_t lit_upper = B.reference_order ? n_live_upper : (lit_expected ? std::min<uint32_t>(n_live_upper, 64u * CHIP_BLOCK) : 1u);
 #define CHIP_EXT(FEAT)                                                                                   \
   {                                                                                                      \
