@@ -525,19 +525,19 @@ __device__ inline bool sphere_hit(const SphereT& s, const TravRay& r, double tmi
 }
 // quad.rs:144-169: t inside [tmin, tmax] inclusive, plane coordinates inside [0,1] inclusive
 __device__ inline bool quad_hit(const DQuad& q, const TravRay& r, double tmin, double tmax, double& t_out, double& alpha, double& beta) {
-  V3 n = ld3(q.n);
-  double denom = dot(n, r.d);
-  if (fabs(denom) < 1e-8) return false;
-  double t = (q.d - dot(n, r.o)) / denom;
-  if (!(tmin <= t && t <= tmax)) return false;
-  V3 p = r.o + (t * r.d);
-  V3 planar = p - ld3(q.q);
-  V3 w = ld3(q.w);
-  alpha = dot(w, cross(planar, ld3(q.v)));
-  beta = dot(w, cross(ld3(q.u), planar));
-  if (!(0.0 <= alpha && alpha <= 1.0) || !(0.0 <= beta && beta <= 1.0)) return false;
-  t_out = t;
-  return true;
+  // quad.rs:128-157 without its early returns: every operand is asked for at once (one memory round trip instead of
+  // two) and the conditions are combined at the end; the arithmetic that decides is the same, a rejected test merely
+  // computes plane coordinates nobody looks at (comparisons with the NaN or infinity of a zero denominator are false)
+  const V3 n = ld3(q.n), qq = ld3(q.q), w = ld3(q.w), v = ld3(q.v), u = ld3(q.u);
+  const double denom = dot(n, r.d);
+  const double t = (q.d - dot(n, r.o)) / denom;
+  const V3 p = r.o + (t * r.d);
+  const V3 planar = p - qq;
+  alpha = dot(w, cross(planar, v));
+  beta = dot(w, cross(u, planar));
+  const bool ok = !(fabs(denom) < 1e-8) && (tmin <= t && t <= tmax) && (0.0 <= alpha && alpha <= 1.0) && (0.0 <= beta && beta <= 1.0);
+  if (ok) t_out = t;
+  return ok;
 }
 
 // disc.rs:111-131: plane hit with t inside [tmin, tmax] inclusive, then the radius test
@@ -1581,14 +1581,17 @@ struct CacheDesc {
   uint32_t stack_entries;    // per-lane stack entries kept in LDS
 };
 // Threads per block of the traversal kernel: with the LDS scene cache one block owns a whole CU's LDS.  Twelve
-// waves (768 threads) leave each of them 168 VGPRs, which the variant with media needs to stay mostly out of scratch
-// memory; the other variants fit (or nearly fit) sixteen waves' 128 and run faster with the extra waves than
-// without the few spills.
+// waves (768 threads) leave each of them 168 VGPRs, which the variants with rotated quads (whose test keeps a whole
+// quad record in registers) and with media need to stay out of scratch memory; the other variants fit (or nearly
+// fit) sixteen waves' 128 and run faster with the extra waves than without the few spills.
+#ifndef CHIP_EXT_BLOCK_QUADROT
+#define CHIP_EXT_BLOCK_QUADROT 768
+#endif
 #ifndef CHIP_EXT_BLOCK_MEDIA
 #define CHIP_EXT_BLOCK_MEDIA 768
 #endif
 __host__ __device__ constexpr int extend_block(uint32_t F, bool CACHE) {
-  return CACHE ? ((F & TF_MEDIA_ANY) ? 512 : ((F & TF_MEDIA) ? CHIP_EXT_BLOCK_MEDIA : 1024)) : CHIP_BLOCK;
+  return CACHE ? ((F & TF_MEDIA_ANY) ? 512 : ((F & TF_MEDIA) ? CHIP_EXT_BLOCK_MEDIA : ((F == (TF_QUADS | TF_XFORM)) ? CHIP_EXT_BLOCK_QUADROT : 1024))) : CHIP_BLOCK;
 }
 // Waves per SIMD the traversal kernel is register-allocated for.  The LDS-cached sphere-scene kernel asks for 6
 // (at most 80 VGPRs) although only 4 of its own waves fit beside its LDS: the registers it leaves free are
