@@ -662,21 +662,23 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   } while (0)
         // the full kernel's form without image / noise texture code: everything (SHADE_ALL) when the scene has no such
         // texture, else everything but the hits on materials that have one, which a second launch of the full kernel takes
-#define CHIP_SHADE_PLAIN(FAST, PASS)                                                                                           \
+#define CHIP_SHADE_PLAIN(FAST, EXT, PASS)                                                                                         \
   do {                                                                                                                         \
-    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, false, false, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
-    else hipLaunchKernelGGL((k_shade_tiles<FAST, false, false, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
+    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, false, EXT, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
+    else hipLaunchKernelGGL((k_shade_tiles<FAST, false, EXT, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
   } while (0)
         if (lean) {
           if (exact_shading) CHIP_SHADE(false, true, false, SHADE_ALL); else CHIP_SHADE(true, true, false, SHADE_ALL);
         } else if (lean_xform) {
           if (exact_shading) CHIP_SHADE(false, true, true, SHADE_ALL); else CHIP_SHADE(true, true, true, SHADE_ALL);
-        } else if (ext) {
-          if (exact_shading) CHIP_SHADE(false, false, true, SHADE_ALL); else CHIP_SHADE(true, false, true, SHADE_ALL);
         } else if (plain_textures) {
-          if (exact_shading) CHIP_SHADE_PLAIN(false, SHADE_ALL); else CHIP_SHADE_PLAIN(true, SHADE_ALL);
+          if (ext) { if (exact_shading) CHIP_SHADE_PLAIN(false, true, SHADE_ALL); else CHIP_SHADE_PLAIN(true, true, SHADE_ALL); }
+          else { if (exact_shading) CHIP_SHADE_PLAIN(false, false, SHADE_ALL); else CHIP_SHADE_PLAIN(true, false, SHADE_ALL); }
+        } else if (ext) {
+          if (exact_shading) CHIP_SHADE_PLAIN(false, true, SHADE_PLAIN_ONLY); else CHIP_SHADE_PLAIN(true, true, SHADE_PLAIN_ONLY);
+          if (exact_shading) CHIP_SHADE(false, false, true, SHADE_RICH_ONLY); else CHIP_SHADE(true, false, true, SHADE_RICH_ONLY);
         } else {
-          if (exact_shading) CHIP_SHADE_PLAIN(false, SHADE_PLAIN_ONLY); else CHIP_SHADE_PLAIN(true, SHADE_PLAIN_ONLY);
+          if (exact_shading) CHIP_SHADE_PLAIN(false, false, SHADE_PLAIN_ONLY); else CHIP_SHADE_PLAIN(true, false, SHADE_PLAIN_ONLY);
           if (exact_shading) CHIP_SHADE(false, false, false, SHADE_RICH_ONLY); else CHIP_SHADE(true, false, false, SHADE_RICH_ONLY);
         }
 #undef CHIP_SHADE_PLAIN

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Renders the other BASELINE configurations once on one GPU (reduced spp, stated) and prints throughput + traversal stats.
-usage: run_configs.py [final] [cornell] [lattice[:n]] [rtiow]"""
+usage: run_configs.py [final] [cornell] [lattice[:n]] [rtiow] [scad]"""
 import importlib, json, os, sys, time
 import torch  # noqa: F401  (shares the HIP runtime, as bench.py does)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,3 +47,5 @@ for a in args:
             sc.commit()
             return sc
         run(f"S5 scad-shaped lattice {n}^3 1920x1080", b, "64 of 256 spp")
+    elif a == "scad":
+        run("scad shapes (spheres, cubes, cylinders, a light) 1280x720", lambda: pkg.scenes.build(gpu, "scad_shapes", width=1280, spp=256, depth=50), "256 spp")
