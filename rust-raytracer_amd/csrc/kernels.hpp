@@ -1591,7 +1591,7 @@ struct CacheDesc {
 #define CHIP_EXT_BLOCK_MEDIA 768
 #endif
 __host__ __device__ constexpr int extend_block(uint32_t F, bool CACHE) {
-  return CACHE ? ((F & TF_MEDIA_ANY) ? 512 : ((F & TF_MEDIA) ? CHIP_EXT_BLOCK_MEDIA : ((F == (TF_QUADS | TF_XFORM)) ? CHIP_EXT_BLOCK_QUADROT : 1024))) : CHIP_BLOCK;
+  return CACHE ? ((F & TF_MEDIA_ANY) ? 512 : ((F & TF_MEDIA) ? CHIP_EXT_BLOCK_MEDIA : (((F & TF_XFORM) && !(F & TF_NO_QUADROT)) ? CHIP_EXT_BLOCK_QUADROT : 1024))) : CHIP_BLOCK;
 }
 // Waves per SIMD the traversal kernel is register-allocated for.  The LDS-cached sphere-scene kernel asks for 6
 // (at most 80 VGPRs) although only 4 of its own waves fit beside its LDS: the registers it leaves free are
