@@ -2,7 +2,7 @@
 # Everything profiles/r02 holds, collected in one call on the GPU box:  tools/collect_round.sh <git-hash>
 #   1. the PMC passes behind bench.py's roofline objects (tools/collect_roofline_profile.sh),
 #   2. rocprofv3 --kernel-trace --stats of the bench command (per-kernel durations),
-#   3. the bench line itself (default flags) and the other configurations.
+#   3. the bench line itself (default flags), the other configurations and a sweep over every scene of scenes.py.
 # Results land in gpurun_out/r02/, to be copied into profiles/r02/.
 set -u
 GIT="${1:-unknown}"
@@ -19,4 +19,6 @@ rm -rf "$OUT/kt"
 cd "$ROOT"
 timeout -k 10 600 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
 timeout -k 10 400 python3 tools/run_configs.py rtiow final cornell lattice:100 > "$OUT/configs.jsonl" 2> "$OUT/configs.err" || { echo "configs failed"; tail -5 "$OUT/configs.err"; exit 1; }
+timeout -k 10 300 python3 tools/run_configs.py scad >> "$OUT/configs.jsonl" 2>> "$OUT/configs.err" || { echo "scad config failed"; exit 1; }
+timeout -k 10 400 python3 tools/run_all_scenes.py 800 256 > "$OUT/all_scenes.jsonl" 2> "$OUT/all_scenes.err" || { echo "scene sweep failed"; tail -5 "$OUT/all_scenes.err"; exit 1; }
 cut -c1-600 "$OUT/bench.json"

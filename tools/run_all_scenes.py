@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Renders every scene of scenes.py once at a small size and prints throughput and the traversal / shading split:
+a sweep that shows which kernel variants a scene runs at what speed.  usage: run_all_scenes.py [width] [spp]"""
+import importlib, json, os, sys, time
+import torch  # noqa: F401
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("rust-raytracer_amd")
+gpu = pkg.load_gpu()
+width = int(sys.argv[1]) if len(sys.argv) > 1 else 800
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+for name in pkg.scenes.SCENES:
+    try:
+        sc = pkg.scenes.build(gpu, name, width=width, spp=spp, depth=50)
+        sc.render_frame(seed=1)
+        t0 = time.perf_counter()
+        img, _, st = sc.render_frame(seed=1, flags=pkg.bindings.RENDER_TIME_KERNELS)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"scene": name, "Mpaths_per_s": round(st["paths"] / dt / 1e6, 1), "segments_per_path": round(st["segments"] / st["paths"], 2),
+                          "visits": round(st["bvh_visits"] / max(1, st["segments"]), 2), "prims": round(st["prim_tests"] / max(1, st["segments"]), 2),
+                          "trav_ms": round(st["ms_trace"], 1), "shade_ms": round(st["ms_shade"], 1), "frame_ms": round(1e3 * dt, 1)}), flush=True)
+    except Exception as e:  # a scene that needs arguments this sweep does not give
+        print(json.dumps({"scene": name, "error": str(e)[:120]}), flush=True)
