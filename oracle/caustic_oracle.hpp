@@ -199,6 +199,11 @@ struct RenderContext {  // lib.rs:34-36
   // Deterministic traversal counters (not in the reference; used to derive the
   // algorithmic bytes per ray segment).
   uint64_t n_bvh_visits = 0, n_prim_tests = 0, n_segments = 0;
+  // How ConstantMedium::hit draws its free-flight sample: 0 = the nearest of its keyed samples (the form the device
+  // shares, see ConstantMedium); 1 = one draw from the stream per test, literally constant_medium.rs:64 (its outcome
+  // depends on the visiting order, so only the reference-order recursion can use it); 2 = a single keyed sample
+  // whatever the number of tests, a deliberately wrong form that tests use as a negative control.
+  int media_mode = 0;
 };
 
 // vector.rs:63-69
@@ -1221,8 +1226,14 @@ struct ConstantMedium : Node {
     if (hit1.t < 0.0) hit1.t = 0.0;
     double ray_length = ray.direction.length();
     double distance_inside_boundary = (hit2.t - hit1.t) * ray_length;
-    double u = ctx.random->rand_keyed(sample_base);
-    for (int j = 1; j < tests; j++) u = std::fmax(u, ctx.random->rand_keyed(sample_base + (uint32_t)j));
+    double u;
+    if (ctx.media_mode == 1) {
+      u = ctx.random->rand();  // constant_medium.rs:64
+    } else {
+      u = ctx.random->rand_keyed(sample_base);
+      if (ctx.media_mode == 0)
+        for (int j = 1; j < tests; j++) u = std::fmax(u, ctx.random->rand_keyed(sample_base + (uint32_t)j));
+    }
     double hit_distance = neg_inv_density * std::log(u);
     if (hit_distance > distance_inside_boundary) return false;
     double t = hit1.t + hit_distance / ray_length;

@@ -36,7 +36,8 @@ struct OrcRenderOpts {  // same field order as chip_render_opts
   uint32_t stratum_offset, stratum_stride;
   uint32_t xmin, xmax, ymin, ymax;
   uint32_t strata_per_batch;  // ignored by the oracle
-  uint32_t flags;             // bit0: use the forward-only (iterative) estimator; low 8 bits of (flags>>8): threads (0 = hw)
+  uint32_t flags;             // bit0: use the forward-only (iterative) estimator; low 8 bits of (flags>>8): threads (0 = hw);
+                              // bits 16-17: RenderContext::media_mode (0 keyed samples, 1 one stream draw per test, 2 negative control)
 };
 
 struct OrcHit {  // same layout as chip_hit
@@ -476,6 +477,7 @@ int orc_render_frame(OrcScene* s, const OrcRenderOpts* opts, double* out_sum, ui
       rng.seed(opts->seed);
       RenderContext ctx;
       ctx.random = &rng;
+      ctx.media_mode = (int)((opts->flags >> 16) & 3u);
       for (;;) {
         Work w;
         {

@@ -130,3 +130,40 @@ def test_gpu_shared_medium_equals_oracle(pkg, oracle, gpu, how, inside):
     o_img, _, so_st = so.render_frame(seed=2, sum_dtype=np.float64)
     assert se["segments"] == so_st["segments"]
     assert (np.abs(e.astype(np.float64) - o_img) > 1e-3 * (1.0 + np.abs(o_img))).mean() < 2e-3
+
+
+# ---- the keyed form against the literal one, as images of the scene whose media sit alone in their hierarchies
+ORC_MEDIA_LITERAL = 1 << 16   # one draw from the stream per test of a medium (constant_medium.rs:64), reference visiting order
+ORC_MEDIA_SINGLE_KEY = 2 << 16  # one keyed sample per medium however often it is tested: wrong on purpose
+
+
+def _final_blocks(oracle, pkg, seed, flags, width=60, spp=144, depth=12):
+    sc = pkg.scenes.build(oracle, "final", width=width, spp=spp, depth=depth)
+    img, _, _ = sc.render_frame(seed=seed, flags=flags)
+    img = img / float(sc.sqrt_spp() ** 2)
+    h, w, _ = img.shape
+    b = 6  # 6 x 6 blocks of pixels
+    blocks = img[: h - h % b, : w - w % b].reshape(b, (h - h % b) // b, b, (w - w % b) // b, 3).mean(axis=(1, 3))
+    return blocks, img.mean(axis=(0, 1))
+
+
+def test_keyed_medium_samples_render_like_literal_stream_draws(oracle, pkg):
+    """Next-Week final scene (crates/cli/src/scene/final_scene.rs): both of its media are the only member of a
+    BoundingVolumeHierarchy span, so the reference tests each twice per world.hit (bvh.rs:22-28), drawing a fresh
+    stream sample every time (constant_medium.rs:64).  The oracle's order-independent form (the nearest of the
+    medium's keyed samples, the one the device shares) must give the same image as that literal form up to Monte
+    Carlo noise; a form that draws one sample per medium must not (it was this test's first failure mode: 13 % off
+    in the fog).  Parity unpinned above the math level: the reference holds no image of this scene."""
+    keyed_a, mean_a = _final_blocks(oracle, pkg, 11, 0)
+    keyed_b, mean_b = _final_blocks(oracle, pkg, 12, 0)
+    literal, mean_l = _final_blocks(oracle, pkg, 13, ORC_MEDIA_LITERAL)
+    single, mean_s = _final_blocks(oracle, pkg, 14, ORC_MEDIA_SINGLE_KEY)
+    noise = np.sqrt(np.mean((keyed_a - keyed_b) ** 2))   # two independent renders of the same form
+    d_lit = np.sqrt(np.mean((0.5 * (keyed_a + keyed_b) - literal) ** 2))
+    d_single = np.sqrt(np.mean((0.5 * (keyed_a + keyed_b) - single) ** 2))
+    assert noise > 0
+    # difference of an independent render from the mean of two has sqrt(1.5 / 2) of the pair's own difference
+    assert d_lit < 1.5 * noise, (d_lit, noise)
+    assert np.all(np.abs(mean_l - 0.5 * (mean_a + mean_b)) < 0.02 * np.abs(mean_l) + 1e-3)
+    # the negative control: the test can tell a wrong sampling form from noise
+    assert d_single > 2.0 * noise, (d_single, noise)
