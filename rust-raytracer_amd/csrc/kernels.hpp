@@ -282,8 +282,9 @@ struct TravStack {
 // Read-only copy of the hottest scene records in LDS: the first n_bvh culling nodes (the tables are in
 // breadth-first order, so these are the top of the tree) and the first n_sph spheres.  A sphere is split into
 // its four 16-byte components stored in separate arrays (component k of record i at [k * cap + i]), which
-// spreads the lanes of a wave over the LDS banks; a culling node is stored as three arrays of (low, high) plane
-// word pairs, one per axis, followed by the array of child words (see load_wnode).
+// spreads the lanes of a wave over the LDS banks; a culling node keeps its first 112 bytes together (a 112-byte
+// stride sends 16 consecutive records to 16 different groups of four banks), so that one address register per axis
+// reaches all of it through the instructions' offset fields (see load_wnode).
 struct NodeCache {
   uint32_t bvh_off, sph_off;  // first uint4 of the BVH / sphere component arrays in g_lds
   uint32_t n_bvh, n_sph;      // records cached
@@ -389,21 +390,24 @@ __device__ inline uint4 lds_read4_at(uint32_t byte) {
   v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
   return v;
 }
-// In a 128-byte record the low and high plane words of an axis are 16 bytes apart in one 32-byte aligned pair, and
-// the LDS copy keeps the pairs together ([axis][record][low, high], then the child words), so the far plane's
-// address is the near plane's with bit 4 flipped.  Global records are addressed with 32-bit byte offsets from the
-// table's base (the host refuses tables of 2^25 nodes or more).
+// In a 128-byte record the low and high plane words of an axis are 16 bytes apart in one 32-byte aligned pair, so
+// the far plane's address is the near plane's with bit 4 flipped; the LDS copy has the same record layout at a
+// 112-byte stride.  Global records are addressed with 32-bit byte offsets from the table's base (the host refuses
+// tables of 2^25 nodes or more).
 template <bool CACHE>
 __device__ inline void load_wnode(const DScene& S, const NodeCache& C, uint32_t idx, const TravRay& r, WNodeRec& n) {
   uint4 q[CHIP_WNODE_U4];
   if (CACHE && idx < C.n_bvh) {
-    const uint32_t axis = C.cap_bvh << 5, base = C.bvh_off << 4;
-    const uint32_t b = idx << 5;
-    const uint32_t nx = b + r.far16[0] + base, ny = b + r.far16[1] + (base + axis), nz = b + r.far16[2] + (base + 2u * axis);
-    q[0] = lds_read4_at(nx); q[1] = lds_read4_at(nx ^ 16u);
-    q[2] = lds_read4_at(ny); q[3] = lds_read4_at(ny ^ 16u);
-    q[4] = lds_read4_at(nz); q[5] = lds_read4_at(nz ^ 16u);
-    q[6] = lds_read4_at((idx << 4) + (base + 3u * axis));
+    // one multiply for the record, one add and one subtract per axis (near plane at +f, far plane at +16 - f); the
+    // rest of each address is a constant that rides in the instruction's offset field
+    const uint32_t rec = __umul24(idx, 16u * CHIP_WNODE_U4) + (C.bvh_off << 4);
+    const uint32_t nx = rec + r.far16[0], fx = rec - r.far16[0];
+    const uint32_t ny = rec + r.far16[1], fy = rec - r.far16[1];
+    const uint32_t nz = rec + r.far16[2], fz = rec - r.far16[2];
+    q[0] = lds_read4_at(nx); q[1] = lds_read4_at(fx + 16u);
+    q[2] = lds_read4_at(ny + 32u); q[3] = lds_read4_at(fy + 48u);
+    q[4] = lds_read4_at(nz + 64u); q[5] = lds_read4_at(fz + 80u);
+    q[6] = lds_read4_at(rec + 96u);
   } else {
     const unsigned char* p = reinterpret_cast<const unsigned char*>(S.wnodes);
     const uint32_t b = idx << 7;
@@ -441,7 +445,7 @@ __device__ inline void ray_set_cull(TravRay& r) {
     // The near plane is the low one for d > 0 and the high one for d < 0; either way its distance (plane - o) / d
     // shrinks when |1/d| does, and the far plane's grows when |1/d| does, so the two multipliers do not depend on
     // the sign: only which plane they are applied to does (far16).
-    const float invf = __frcp_rn((float)d[a]);
+    const float invf = __builtin_amdgcn_rcpf((float)d[a]);  // v_rcp_f32 (1 ulp, inside CHIP_CULL_DELTA) instead of a correctly rounded division
     r.m_n[a] = invf * (1.0f - CHIP_CULL_DELTA);
     r.m_f[a] = invf * (1.0f + CHIP_CULL_DELTA);
     r.c_n[a] = f32_below(-(o[a] * (double)r.m_n[a]));
@@ -1009,11 +1013,11 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
 // then differ from the reference's arithmetic in the last digits, which only matters statistically.
 // CHIP_RENDER_EXACT_SHADING selects the variants that keep the reference's f64 operation order.
 __device__ inline double fast_rsqrt(double x) {
-  double y = (double)__frsqrt_rn((float)x);
+  double y = (double)__builtin_amdgcn_rsqf((float)x);  // v_rsq_f32: a seed needs no correct rounding
   return y * (1.5 - 0.5 * x * y * y);
 }
 __device__ inline double fast_rcp(double x) {
-  double y = (double)__frcp_rn((float)x);
+  double y = (double)__builtin_amdgcn_rcpf((float)x);  // v_rcp_f32
   return y * (2.0 - x * y);
 }
 __device__ inline V3 fast_unit(V3 a) { return a * fast_rsqrt(len2(a)); }
@@ -1617,11 +1621,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
     for (uint32_t i = threadIdx.x; i < cd.n_bvh; i += blockDim.x) {
       const uint4* p = reinterpret_cast<const uint4*>(S.wnodes + i);
 #pragma unroll
-      for (int a = 0; a < 3; a++) {
-        g_lds[2u * (a * cd.n_bvh + i)] = p[2 * a];
-        g_lds[2u * (a * cd.n_bvh + i) + 1u] = p[2 * a + 1];
-      }
-      g_lds[6u * cd.n_bvh + i] = p[6];
+      for (int k = 0; k < CHIP_WNODE_U4; k++) g_lds[(uint32_t)CHIP_WNODE_U4 * i + k] = p[k];
     }
     const uint32_t so = (uint32_t)CHIP_WNODE_U4 * cd.n_bvh;
     for (uint32_t i = threadIdx.x; i < cd.n_sph; i += blockDim.x) {

@@ -167,3 +167,17 @@ def test_keyed_medium_samples_render_like_literal_stream_draws(oracle, pkg):
     assert np.all(np.abs(mean_l - 0.5 * (mean_a + mean_b)) < 0.02 * np.abs(mean_l) + 1e-3)
     # the negative control: the test can tell a wrong sampling form from noise
     assert d_single > 2.0 * noise, (d_single, noise)
+
+
+@pytest.mark.gpu
+def test_gpu_final_scene_renders_like_literal_stream_draws(oracle, gpu, pkg):
+    """The device's render of the Next-Week final scene (keyed medium samples, ordered traversal) against the oracle's
+    literal form (reference visiting order, one stream draw per medium test), independently seeded: equal up to
+    Monte Carlo noise, block by block."""
+    dev_a, mean_a = _final_blocks(gpu, pkg, 21, 0)
+    dev_b, mean_b = _final_blocks(gpu, pkg, 22, 0)
+    literal, mean_l = _final_blocks(oracle, pkg, 13, ORC_MEDIA_LITERAL)
+    noise = np.sqrt(np.mean((dev_a - dev_b) ** 2))
+    d_lit = np.sqrt(np.mean((0.5 * (dev_a + dev_b) - literal) ** 2))
+    assert noise > 0 and d_lit < 1.5 * noise, (d_lit, noise)
+    assert np.all(np.abs(mean_l - 0.5 * (mean_a + mean_b)) < 0.02 * np.abs(mean_l) + 1e-3)
