@@ -438,8 +438,11 @@ __device__ inline float f32_below(double v) {
 // Culling form for the ray currently in r.o / r.d.  Every direction component is finite and well away from zero here
 // (has_zero_component() sends the other rays to the literal traversal), so each axis culls and a box with its low planes
 // above its high planes (an unused child slot) is missed whatever the ray.
-__device__ inline void ray_set_cull(TravRay& r) {
+// Returns whether every component's reciprocal slope is an ordinary f32 of moderate size (the f32 counterpart of
+// has_zero_component(), which a caller that computes the form anyway can use in its place).
+__device__ inline bool ray_set_cull(TravRay& r) {
   const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+  bool ok = true;
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     // The near plane is the low one for d > 0 and the high one for d < 0; either way its distance (plane - o) / d
@@ -448,10 +451,16 @@ __device__ inline void ray_set_cull(TravRay& r) {
     const float invf = __builtin_amdgcn_rcpf((float)d[a]);  // v_rcp_f32 (1 ulp, inside CHIP_CULL_DELTA) instead of a correctly rounded division
     r.m_n[a] = invf * (1.0f - CHIP_CULL_DELTA);
     r.m_f[a] = invf * (1.0f + CHIP_CULL_DELTA);
-    r.c_n[a] = f32_below(-(o[a] * (double)r.m_n[a]));
-    r.c_f[a] = f32_above(-(o[a] * (double)r.m_f[a]));
+    // -o * m in f32: the conversion of o and the product are each off by at most 2^-24 of the result, so moving
+    // the product by 2^-22 of itself puts it safely on the conservative side
+    const float of = (float)o[a];
+    const float pn = -(of * r.m_n[a]), pf = -(of * r.m_f[a]);
+    r.c_n[a] = fmaf(-fabsf(pn), 2.3841858e-07f, pn);
+    r.c_f[a] = fmaf(fabsf(pf), 2.3841858e-07f, pf);
     r.far16[a] = invf > 0.0f ? 0u : 16u;
+    ok = ok && fabsf(invf) > 1.0e-18f && fabsf(invf) < 1.0e18f;  // (false for NaN)
   }
+  return ok;
 }
 
 // aabb.rs:195-228.  The per-axis early return is folded into one final test: the
@@ -629,10 +638,12 @@ __device__ inline bool sphere_hit_incl(const SphereT& s, const TravRay& r, doubl
 }
 
 template <bool ORD = false>
-__device__ inline void ray_set_inv(TravRay& r) {
-  if (ORD) ray_set_cull(r);
+__device__ inline bool ray_set_inv(TravRay& r) {
+  bool ok = true;
+  if (ORD) ok = ray_set_cull(r);
   else r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
   r.dd = len2(r.d);
+  return ok;
 }
 // Scene features a traversal / shade instantiation handles (scenes lacking a feature run a leaner variant):
 // quads & groups | Translate & Rotate | ConstantMedium | discs, cone walls & Scale
@@ -1699,7 +1710,10 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
           else ray_load(ray_in + entry, r.wo, r.wd, r.time, id);
           const bool dead = !B0 && id == CHIP_DEAD_ID;  // reserved by the last shading pass but left empty
           if (dead) *reinterpret_cast<uint4*>(P.hit + entry) = make_uint4(0u, 0u, NREF_DEAD, 0u);
-          const bool to_literal = !dead && ORD && (B.reference_order || has_zero_component(r.wd));
+          // the culling form is computed first: it also tells whether the ordered traversal can take the ray
+          r.o = r.wo; r.d = r.wd;
+          const bool ordinary = ray_set_inv<ORD>(r);
+          const bool to_literal = !dead && ORD && (B.reference_order || !ordinary);
           if (ORD) {  // the literal queue takes these rays (appended with one atomic per wave)
             const unsigned long long ml = __ballot(to_literal);
             if (ml) {
@@ -1711,8 +1725,6 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
             }
           }
           if (!to_literal && !dead) {
-            r.o = r.wo; r.d = r.wd;
-            ray_set_inv<ORD>(r);
             r.capf = INFINITY;
             if (F & TF_MEDIA) {
               uint32_t x, y, pixel, stratum;
