@@ -10,7 +10,9 @@ the timed region, so inputs are resident in HBM.
 
 Prints ONE JSON line on rank 0 (metric = whole-job path-samples/s).  Besides the contract's fields:
   roofline      the dominant kernel (closest-hit traversal) against the resource that bounds it on this workload,
-                vector-ALU issue: lane-operations per second.  The work per ray segment comes from a committed
+                vector-ALU issue: lane-operations per second against the nominal peak (the rate of plain f32
+                multiply-adds), and under `issue` the occupancy of the issue port once every instruction is priced at
+                the cost measured for its kind.  The work per ray segment comes from a committed
                 rocprofv3 PMC summary (profiles/r02/roofline_profile.json, with the git hash it was taken at and the
                 hash of the kernel source it describes); the segments and the launch durations are measured live.
   roofline_s5   the same kernel on the one configuration whose scene tables do not fit the caches (the 100^3
@@ -41,10 +43,13 @@ BYTES_SPHERE = 64       # the part of a sphere record a test reads: centre, moti
 BYTES_INSTANCE = 128    # DTranslate with its sphere inlined: one record per instanced-sphere test
 BYTES_SEGMENT_STATE = 64 + 16  # PathRay record read (not at bounce 0, whose rays are computed), PathHit record written
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
-# Vector-ALU issue peak: a SIMD issues one plain wave64 instruction per 4 cycles (16 lanes per clock; the 157 TFLOP/s
-# fp32 figure of the data sheet is this rate times 2 for packed f32 times 2 for multiply-add):
-# 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.
-VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+# Vector-ALU peak: a CDNA4 SIMD is 32 lanes wide, so a wave64 instruction of the fast kind (plain f32 multiply-add, add,
+# multiply; 32-bit integer add and logic) issues over 2 cycles: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (the data
+# sheet's 157 TFLOP/s fp32 is this rate times 2 for multiply-add).  Every other kind of instruction (f64, min / max,
+# selects, compares, conversions, 3-operand integer forms), i.e. four fifths of what the traversal executes, issues at
+# little more than half that rate (tools/micro/valu_clock measures both; the profile carries the figures), so the
+# kernel's own instruction mix cannot reach this peak: `issue` below prices the mix.
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 PROFILE_JSON = os.path.join(ROOT, "profiles", "r02", "roofline_profile.json")
 KERNEL_SOURCES = [os.path.join(ROOT, "rust-raytracer_amd", "csrc", f) for f in ("kernels.hpp", "device_scene.h")]
 
@@ -250,15 +255,19 @@ def main():
             "unit": "Tlane-op/s",
             "frac": achieved / VALU_PEAK_TLANEOPS if achieved else None,
             "traffic": (p2.get("hbm_bytes_per_segment") * seg / launches) if (usable and p2.get("hbm_bytes_per_segment")) else None,
-            "definition": "achieved = vector-ALU lane-operations per ray segment (SQ_THREAD_CYCLES_VALU: active lanes x issue slots, from the "
-                          "profile) x segments of the timed launches / their summed HIP-event durations; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz. "
-                          "With two batches in flight a launch shares the device with the other batch's shading, so durations are longer than alone.",
+            "definition": "achieved = vector-ALU lane-operations per ray segment (SQ_THREAD_CYCLES_VALU: active lanes x instructions, from the "
+                          "profile) x segments of the timed launches / their summed HIP-event durations; peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz, "
+                          "the rate of plain f32 multiply-adds. With two batches in flight a launch shares the device with the other batch's "
+                          "shading, so durations are longer than alone.",
+            # what the kernel's own instruction mix allows: measured issue cost per instruction kind x the mix, against the SIMD
+            # cycles one instruction took with the kernel alone on the device (all from the committed profile)
+            "issue": p2.get("valu_issue") if usable else None,
             "profile": {
                 "path": os.path.relpath(PROFILE_JSON, ROOT),
                 "git": (prof or {}).get("git"),
                 "kernel_source_sha256_16": (prof or {}).get("kernel_source_sha256_16"),
                 "note": prof_note or ("figures apply to the default workload only" if not default_workload else None),
-                "alone": {k: p2.get(k) for k in ("valu_busy", "lane_utilisation", "frac_of_valu_peak_alone", "avg_launch_ms_alone")},
+                "alone": {k: p2.get(k) for k in ("lane_utilisation", "frac_of_nominal_valu_peak_alone", "wave_wait_share")},
             },
             "avg_launch_ms": ms_trace / launches if launches else None,
             "launches": launches,

@@ -10,7 +10,7 @@ ROOT="$GRAFT_REPO_ROOT"
 OUT="$ROOT/gpurun_out/r02"
 rm -rf "$OUT"; mkdir -p "$OUT"
 timeout -k 10 900 "$ROOT/tools/collect_roofline_profile.sh" "$GIT" > "$OUT/collect_roofline.log" 2>&1 || { echo "roofline passes failed"; tail -5 "$OUT/collect_roofline.log"; exit 1; }
-cp "$ROOT/gpurun_out/roofline_profile/roofline_profile.json" "$ROOT/gpurun_out/roofline_profile/pmc_s2_summary.txt" "$ROOT/gpurun_out/roofline_profile/pmc_s5_summary.txt" "$OUT/"
+cp "$ROOT/gpurun_out/roofline_profile/roofline_profile.json" "$ROOT/gpurun_out/roofline_profile/pmc_s2_summary.txt" "$ROOT/gpurun_out/roofline_profile/pmc_s5_summary.txt" "$ROOT/gpurun_out/roofline_profile/valu_issue_cost.txt" "$OUT/"
 mkdir -p "$ROOT/profiles/r02" && cp "$OUT/roofline_profile.json" "$ROOT/profiles/r02/"   # (the box's copy: what the bench runs below read)
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-s5 --no-rank-share > "$OUT/bench_under_kernel_trace.log" 2>&1 || { echo "kernel trace failed"; tail -5 "$OUT/bench_under_kernel_trace.log"; exit 1; }

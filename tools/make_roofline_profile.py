@@ -39,12 +39,45 @@ def last_json(path):
     raise SystemExit(f"no JSON line in {path}")
 
 
-def figures(c, segments):
+def issue_costs(path):
+    """Cycles per wave64 instruction per SIMD at 4 waves per SIMD, by instruction kind, from tools/micro/valu_clock."""
+    cost = {}
+    for line in open(path):
+        m = re.match(r"(v_\S+)\s.*4 wave/SIMD:\s+([0-9.]+) cyc/instr", line)
+        if m:
+            cost[m.group(1)] = float(m.group(2))
+    return cost
+
+
+def figures(c, segments, cost):
     gui = c["GRBM_GUI_ACTIVE"][0]      # summed over the 8 XCDs and the dispatches
-    simd_slots = gui / 8 / 4 * 1024     # issue slots (4 cycles each) of the chip's 1024 SIMDs while the kernel ran
+    simd_cycles = gui / 8 * 1024        # cycles of the chip's 1024 SIMDs while the kernel ran
+    simd_slots = simd_cycles / 4        # 4-cycle issue slots (the unit of the SQ_*_VALU counters)
     lane_ops = c["SQ_THREAD_CYCLES_VALU"][0]
     active = c["SQ_ACTIVE_INST_VALU"][0]
+    insts = c["SQ_INSTS_VALU"][0]
+    # Issue cost of the kernel's own instruction mix: plain f32 multiply-adds, adds and multiplies issue at the fast rate
+    # the microbenchmark measures for v_fma_f32; everything else (f64, min / max / max3, selects, compares,
+    # conversions, 3-operand integer forms) at the slow one.  32-bit integer adds and logic also issue fast but the
+    # counters do not separate them from the slow integer forms, so they are priced as slow: the mix cost is an upper
+    # bound and the occupancy figure below a lower bound.
+    fast = c["SQ_INSTS_VALU_FMA_F32"][0] + c["SQ_INSTS_VALU_ADD_F32"][0] + c["SQ_INSTS_VALU_MUL_F32"][0]
+    # (the mix pass is a run of its own; its total is not collected, so shares are taken against the first run's count)
+    fast_share = min(1.0, fast / insts)
+    c_fast = cost["v_fma_f32"]
+    c_slow = sum(cost[k] for k in ("v_fma_f64", "v_max3_f32", "v_min_u32", "v_cndmask_b32")) / 4.0
+    mix_cost = fast_share * c_fast + (1.0 - fast_share) * c_slow
+    cycles_per_inst = simd_cycles / insts
     return {
+        "valu_issue": {
+            "instructions": insts,
+            "share_f32_fma_add_mul": fast_share,
+            "measured_cost_cycles": {"fast (v_fma_f32)": c_fast, "slow (mean of v_fma_f64, v_max3_f32, v_min_u32, v_cndmask_b32)": c_slow},
+            "mix_cost_cycles_per_instruction": mix_cost,
+            "simd_cycles_per_instruction_alone": cycles_per_inst,
+            "issue_occupancy_alone": mix_cost / cycles_per_inst,
+        },
+        "frac_of_nominal_valu_peak_alone": lane_ops / (64.0 * simd_cycles / 2.0),
         "segments": segments,
         "launches": c["SQ_THREAD_CYCLES_VALU"][1],
         "valu_lane_ops_per_segment": lane_ops / segments,
@@ -65,11 +98,12 @@ def main():
     d, git = sys.argv[1], sys.argv[2]
     b = last_json(os.path.join(d, "s2", "sq.log"))
     seg2 = b["roofline"]["segments_per_path"] * b["config"]["path_samples_per_step"] * b["steps"]
-    s2 = figures(counters(os.path.join(d, "pmc_s2_summary.txt"), "k_extend<0u, true, true"), seg2)
+    cost = issue_costs(os.path.join(d, "valu_issue_cost.txt"))
+    s2 = figures(counters(os.path.join(d, "pmc_s2_summary.txt"), "k_extend<0u, true, true"), seg2, cost)
     s2["workload"] = b["config"]["workload"] + " (one frame under rocprofv3 --pmc, kernels serialised)"
     l = last_json(os.path.join(d, "s5", "sq.log"))
     seg5 = 2 * l["segments_per_path"] * 1920 * 1080 * l["spp"]  # run_configs renders the frame twice
-    s5 = figures(counters(os.path.join(d, "pmc_s5_summary.txt"), "k_extend<35u, true, true"), seg5)
+    s5 = figures(counters(os.path.join(d, "pmc_s5_summary.txt"), "k_extend<35u, true, true"), seg5, cost)
     s5["workload"] = l["config"] + f", {l['spp']} spp, two renders under rocprofv3 --pmc"
     out = {
         "git": git,
@@ -77,7 +111,10 @@ def main():
         "collected": datetime.date.today().isoformat(),
         "how": "tools/collect_roofline_profile.sh: separate rocprofv3 --pmc runs for the SQ, FETCH_SIZE and WRITE_SIZE groups; "
                "counters summed over the traversal kernel's instantiations (bounce 0 and later bounces); FETCH_SIZE doubled "
-               "(gfx950 reports half of a wide read stream); SQ_ACTIVE_INST_VALU / SQ_THREAD_CYCLES_VALU count 4-cycle issue slots",
+               "(gfx950 reports half of a wide read stream); SQ_ACTIVE_INST_VALU / SQ_THREAD_CYCLES_VALU count 4-cycle issue slots; "
+               "instruction-kind counters in a run of their own; issue costs per instruction kind from tools/micro/valu_clock "
+               "(valu_issue_cost.txt: cycles per wave64 instruction per SIMD with 4 waves per SIMD on every CU)",
+        "valu_issue_cost_cycles_4_waves_per_simd": cost,
         "s2": s2,
         "s5": s5,
     }

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
-enum Kind { FMA32, FMA64, ADD64, IADD, MINU, CNDMASK, MAX3, PKFMA, MAX32, CMP32, AND32, ANDOR, MUL64, MADU24, CVT };
+enum Kind { FMA32, FMA64, ADD64, IADD, MINU, CNDMASK, MAX3, PKFMA, MAX32, CMP32, AND32, ANDOR, MUL64, MADU24, CVT, ADD32, MUL32, LSHL };
 template <int K>
 __global__ void __launch_bounds__(1024) k_loop(double* out, int iters) {
   float f[8]; double d[8]; unsigned u[8];
@@ -32,6 +32,9 @@ __global__ void __launch_bounds__(1024) k_loop(double* out, int iters) {
       if (K == MUL64) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[j]) : "v"(dm));
       if (K == MADU24) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
       if (K == CVT) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[j]) : "v"(d[j]));
+      if (K == ADD32) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[j]) : "v"(fc));
+      if (K == MUL32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[j]) : "v"(fm));
+      if (K == LSHL) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(u[j]));
       if (K == PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(d[j]) : "v"(dm));
     }
   }
@@ -65,6 +68,9 @@ int main() {
   double* out;
   hipMalloc(&out, sizeof(double) * 256 * 1024);
   run<FMA32>("v_fma_f32", out);
+  run<ADD32>("v_add_f32", out);
+  run<MUL32>("v_mul_f32", out);
+  run<LSHL>("v_lshlrev_b32", out);
   run<MAX3>("v_max3_f32", out);
   run<PKFMA>("v_pk_fma_f32", out);
   run<FMA64>("v_fma_f64", out);
