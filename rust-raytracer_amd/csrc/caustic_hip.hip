@@ -364,6 +364,7 @@ static int plan_render(chip_scene* s, const chip_render_opts* o, RenderPlan& pl)
 // the LDS-cached form (one persistent block per CU; top of the BVH and leading spheres in LDS).
 struct ExtendPlan {
   bool cache;
+  bool small;  // bare spheres, everything LDS-resident, few enough for 11-bit references: the compact form (k_extend_small)
   CacheDesc cd;
   uint32_t block, lds_bytes;
 };
@@ -387,7 +388,21 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
     budget -= p.cd.n_bvh * node_bytes;
     p.cd.n_sph = (uint32_t)std::min<size_t>(s->flat.spheres.size(), budget / sphere_bytes);
     p.lds_bytes = node_bytes * p.cd.n_bvh + sphere_bytes * p.cd.n_sph + stack_bytes;
+    // the compact form: planned on its own (4-byte stack words, the whole scene cached or not at all)
+    const char* e_no_small = getenv("CHIP_NO_SMALL_FORM");
+    const bool no_small = e_no_small && *e_no_small == '1';
+    uint32_t small_entries = 16;
+    if (const char* es = getenv("CHIP_SMALL_STACK")) { int v = atoi(es); if (v >= 4 && v <= 24) small_entries = (uint32_t)v; }
+    const size_t small_bytes = node_bytes * s->flat.n_wide + sphere_bytes * s->flat.spheres.size() + (size_t)small_entries * 4 * p.block;
+    p.small = !no_small && feat == 0 && s->flat.n_wide <= CHIP_SM_MAX && s->flat.spheres.size() <= CHIP_SM_MAX && small_bytes <= kLdsBytes;
+    if (p.small) {
+      p.cd.stack_entries = small_entries;
+      p.cd.n_bvh = (uint32_t)s->flat.n_wide;
+      p.cd.n_sph = (uint32_t)s->flat.spheres.size();
+      p.lds_bytes = (uint32_t)small_bytes;
+    }
   } else {
+    p.small = false;
     p.block = CHIP_BLOCK;
     p.cd.stack_entries = CHIP_STACK_LDS;
     p.cd.n_bvh = p.cd.n_sph = 0;
@@ -419,6 +434,21 @@ static int launch_extend_b(const DeviceState& D, const PathPool& P, const Extend
     lds_bytes = p.cd.stack_entries * 8u * threads;
   }
   hipLaunchKernelGGL((k_extend<F, CACHE, ORD, B0>), dim3(blocks), dim3(threads), lds_bytes, st, D.dscene, P, B, bounce, p.cd, lit_pass);
+  return 0;
+}
+template <bool B0>
+static int launch_extend_small(const DeviceState& D, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
+                               uint32_t bounce) {
+  static std::atomic<uint64_t> attr_done{0};
+  const uint64_t bit = 1ull << ((unsigned)D.device & 63u);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_extend_small<B0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  if (p.block != (uint32_t)extend_block(0, true)) return fail("internal: traversal launch planned for another kernel variant");
+  uint32_t blocks = (n_live_upper + p.block - 1) / p.block;
+  blocks = std::max(1u, std::min(blocks, (uint32_t)D.n_cus));
+  hipLaunchKernelGGL((k_extend_small<B0>), dim3(blocks), dim3(p.block), p.lds_bytes, st, D.dscene, P, B, bounce, p.cd);
   return 0;
 }
 template <uint32_t F, bool CACHE, bool ORD>
@@ -462,6 +492,11 @@ static int launch_extend(const chip_scene* s, const DeviceState& D, const PathPo
                       : launch_extend_t<FEAT, false, true>(D, P, p, n_live_upper, st, B, bounce, 0);     \
     if (rc_) return rc_;                                                                                 \
     return launch_extend_t<FEAT, false, false>(D, P, lit, lit_upper, st, B, bounce, 1);                  \
+  }
+  if (feat == 0 && p.cache && p.small) {
+    int rc_ = bounce == 0 ? launch_extend_small<true>(D, P, p, n_live_upper, st, B, bounce) : launch_extend_small<false>(D, P, p, n_live_upper, st, B, bounce);
+    if (rc_) return rc_;
+    return launch_extend_t<0, false, false>(D, P, lit, lit_upper, st, B, bounce, 1);
   }
   switch (feat) {
     case 0: CHIP_EXT(0)

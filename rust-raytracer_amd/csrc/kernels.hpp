@@ -1762,6 +1762,242 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
 }
 
 
+// ------------------------------------------------------------------ compact form for small sphere scenes
+// A scene of bare spheres whose whole culling tree and sphere table are LDS-resident, with fewer than 1023 of either
+// (the RTIOW scenes), is traversed with 11-bit node references: bit 10 says "sphere", the low bits are the index,
+// 0x7FF stands for none.  A child's sort key then carries the reference itself in its low 11 bits (the culling
+// record's child words are stored as such tags), under the entry distance truncated to its upper 21 bits: picking the
+// nearest child is one AND instead of a three-select pick by slot number, a deferred child is pushed as its key, one
+// 4-byte stack word, and a popped word is dropped when its (rounded-down) distance lies beyond the closest hit.
+// Same visits up to the order of children whose distances agree to 12 bits, same hits, same ties (tie_wins).
+#define CHIP_SM_SPHERE 0x400u
+#define CHIP_SM_NONE 0x7FFu
+#define CHIP_SM_MAX 1023u  // nodes / spheres such a scene may hold (index 0x3FF with the sphere bit would read as none)
+typedef __attribute__((address_space(3))) uint32_t* lds_u1_t;
+// The stack lives in LDS only: a ray whose descent would need more entries than that is flagged and traced by the
+// literal pass instead (the caller hands it over like a ray with a zero direction component), which keeps every
+// push free of branches.
+struct SmallStack {
+  lds_u1_t lds;      // this lane's column: one 4-byte word per entry
+  int sp, lds_cap;
+  uint32_t stride4;  // bytes between consecutive entries of one lane
+  uint32_t overflow;
+};
+__host__ __device__ inline uint32_t small_ref(nref_t x) {
+  if (x == NREF_NONE) return CHIP_SM_NONE;
+  return (NREF_KIND(x) == NK_SPHERE ? CHIP_SM_SPHERE : 0u) | (NREF_INDEX(x) & 0x3FFu);
+}
+// Writes the key into the next free entry and keeps it only if it names a child (a culled child's key is all ones):
+// no branch.  The caller has made sure that up to three entries are free (sm_room).
+__device__ inline void sm_push(SmallStack& s, uint32_t key) {
+  *(lds_u1_t)((lds_b_t)s.lds + __umul24((uint32_t)s.sp, s.stride4)) = key;
+  s.sp += key != 0xFFFFFFFFu ? 1 : 0;
+}
+__device__ inline void sm_room(SmallStack& s) {
+  if (s.sp > s.lds_cap - 3) {
+    s.sp = s.lds_cap - 3;
+    s.overflow = 1;
+  }
+}
+__device__ inline uint32_t sm_pop(SmallStack& s, float capf) {
+  for (;;) {
+    if (s.sp <= 0) return CHIP_SM_NONE;
+    s.sp--;
+    const uint32_t key = *(lds_u1_t)((lds_b_t)s.lds + __umul24((uint32_t)s.sp, s.stride4));
+    if (__uint_as_float(key & ~CHIP_SM_NONE) <= capf) return key & CHIP_SM_NONE;
+  }
+}
+// The ordered closest-hit loop of traverse<0, ...> on compact references (see there for the descent scheduling).
+template <bool YIELD>
+__device__ void traverse_small(const DScene& S, const NodeCache& C, uint32_t& node, TravRay& r, double tmin, double& best_t, nref_t& best,
+                               SmallStack& st, TravCounters& cnt, int yield_below) {
+  constexpr uint32_t DEN = CHIP_DESCENT_DEN_SPHERES;
+  for (;;) {
+    for (;;) {
+      const bool inner = node < CHIP_SM_SPHERE;
+      const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner)), n_here = (uint32_t)__popcll(__ballot(1));
+      if (n_inner == 0u || n_inner * DEN < n_here) break;
+      if (!inner) continue;
+      const uint32_t rec = __umul24(node, 16u * CHIP_WNODE_U4) + (C.bvh_off << 4);
+      const uint32_t nx = rec + r.far16[0], fx = rec - r.far16[0];
+      const uint32_t ny = rec + r.far16[1], fy = rec - r.far16[1];
+      const uint32_t nz = rec + r.far16[2], fz = rec - r.far16[2];
+      const uint4 qnx = lds_read4_at(nx), qfx = lds_read4_at(fx + 16u), qny = lds_read4_at(ny + 32u), qfy = lds_read4_at(fy + 48u),
+                  qnz = lds_read4_at(nz + 64u), qfz = lds_read4_at(fz + 80u), tag = lds_read4_at(rec + 96u);
+      cnt.bvh++;
+      float near_x[4], far_x[4], near_y[4], far_y[4], near_z[4], far_z[4];
+      u4_to_f4(qnx, near_x); u4_to_f4(qfx, far_x); u4_to_f4(qny, near_y); u4_to_f4(qfy, far_y); u4_to_f4(qnz, near_z); u4_to_f4(qfz, far_z);
+      const uint32_t tg[4] = {tag.x, tag.y, tag.z, tag.w};
+      uint32_t key[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float x0 = fmaf(near_x[k], r.m_n[0], r.c_n[0]), x1 = fmaf(far_x[k], r.m_f[0], r.c_f[0]);
+        const float y0 = fmaf(near_y[k], r.m_n[1], r.c_n[1]), y1 = fmaf(far_y[k], r.m_f[1], r.c_f[1]);
+        const float z0 = fmaf(near_z[k], r.m_n[2], r.c_n[2]), z1 = fmaf(far_z[k], r.m_f[2], r.c_f[2]);
+        const float en = fmaxf(__builtin_fmaxf(__builtin_fmaxf(x0, y0), z0), CHIP_CULL_TMIN);
+        const float ex = fminf(__builtin_fminf(__builtin_fminf(x1, y1), z1), r.capf);
+        key[k] = en <= ex ? ((__float_as_uint(en) & ~CHIP_SM_NONE) | tg[k]) : 0xFFFFFFFFu;
+      }
+#define CHIP_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
+      CHIP_CSWAP(0, 1) CHIP_CSWAP(2, 3) CHIP_CSWAP(0, 2) CHIP_CSWAP(1, 3) CHIP_CSWAP(1, 2)
+#undef CHIP_CSWAP
+      if (key[0] == 0xFFFFFFFFu) {
+        node = sm_pop(st, r.capf);
+      } else {
+        sm_room(st);
+        if (__any(key[2] != 0xFFFFFFFFu)) {  // three or four children in reach: rare enough to be worth the branch
+          sm_push(st, key[3]);
+          sm_push(st, key[2]);
+        }
+        sm_push(st, key[1]);
+        node = key[0] & CHIP_SM_NONE;
+      }
+    }
+    if (node == CHIP_SM_NONE) break;
+    if (node >= CHIP_SM_SPHERE) {  // (a lane still at a culling node sits this round out)
+      const uint32_t idx = node & 0x3FFu;
+      cnt.prim++;
+      SphereRec sp;
+      load_sphere<true>(S, C, idx, sp);
+      double t;
+      if (sphere_hit_incl(sp, r, tmin, best_t, t)) {
+        const nref_t ref = NREF(NK_SPHERE, idx);
+        if (t < best_t || tie_wins(S, ref, best)) {
+          best_t = t;
+          best = ref;
+          r.best_mat = sp.mat;
+          r.capf = f32_above(best_t);
+        }
+      }
+      node = sm_pop(st, r.capf);
+    }
+    if (YIELD && __popcll(__ballot(1)) < yield_below) break;
+  }
+}
+
+// k_extend<0, true, true, B0> on compact references: the same queue handling (chunks, refills, literal hand-over),
+// the LDS copy of a culling record with its child words turned into tags, 4-byte stack words.
+template <bool B0>
+__global__ void __launch_bounds__(extend_block(0, true), extend_min_waves(0, true)) k_extend_small(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg, CacheDesc cd) {
+  const uint32_t bounce = B0 ? 0u : bounce_arg;
+  // LDS layout: [7 x n_bvh uint4: culling records][4 x n_sph uint4: spheres][stack_entries x blockDim 4-byte words]
+  const NodeCache C{0u, (uint32_t)CHIP_WNODE_U4 * cd.n_bvh, cd.n_bvh, cd.n_sph, cd.n_bvh, cd.n_sph};
+  uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
+  const uint32_t n_live = ctr[0];
+  if ((size_t)blockIdx.x * 64u >= n_live) return;
+  for (uint32_t i = threadIdx.x; i < cd.n_bvh; i += blockDim.x) {
+    const uint4* p = reinterpret_cast<const uint4*>(S.wnodes + i);
+#pragma unroll
+    for (int k = 0; k < 6; k++) g_lds[(uint32_t)CHIP_WNODE_U4 * i + k] = p[k];
+    const uint4 ch = p[6];
+    g_lds[(uint32_t)CHIP_WNODE_U4 * i + 6u] = make_uint4(small_ref(ch.x), small_ref(ch.y), small_ref(ch.z), small_ref(ch.w));
+  }
+  const uint32_t so = (uint32_t)CHIP_WNODE_U4 * cd.n_bvh;
+  for (uint32_t i = threadIdx.x; i < cd.n_sph; i += blockDim.x) {
+    const uint4* p = reinterpret_cast<const uint4*>(S.spheres + i);
+    g_lds[so + i] = p[0]; g_lds[so + cd.n_sph + i] = p[1]; g_lds[so + 2 * cd.n_sph + i] = p[2]; g_lds[so + 3 * cd.n_sph + i] = p[3];
+  }
+  __syncthreads();
+  const PathRay* ray_in = P.ray[bounce & 1];
+  uint32_t* cursor = &ctr[CHIP_CTR_CURSOR];
+  const uint32_t lane = __lane_id();
+  SmallStack st;
+  st.lds = (lds_u1_t)(g_lds + (CHIP_WNODE_U4 * cd.n_bvh + 4u * cd.n_sph)) + threadIdx.x;
+  st.overflow = 0;
+  st.sp = 0;
+  st.lds_cap = (int)cd.stack_entries;
+  st.stride4 = 4u * blockDim.x;
+  TravCounters cnt{0, 0};
+  uint32_t nseg = 0;
+  bool has = false;
+  uint32_t entry = 0, draws = 0;
+  TravRay r;
+  r.wo = r.wd = r.o = r.d = r.inv = mk(0, 0, 0);
+  r.time = 0;
+  double best_t = INFINITY;
+  nref_t best = NREF_NONE;
+  uint32_t node = CHIP_SM_NONE;
+  const uint32_t root = small_ref(S.ord_root);
+  const uint32_t n_waves = gridDim.x * (blockDim.x / 64);
+  uint32_t chunk = (n_live / (n_waves * 4u)) & ~63u;
+  chunk = chunk < 64u ? 64u : (chunk > 2048u ? 2048u : chunk);
+  uint32_t w_next = 0, w_end = 0;
+  bool exhausted = false;
+  for (;;) {
+    if (has && node == CHIP_SM_NONE) {
+      if (st.overflow) {  // the descent ran out of stack: the literal pass traces this ray
+        st.overflow = 0;
+        P.q_lit[atomicAdd(&ctr[CHIP_CTR_LIT], 1u)] = entry;
+      } else {
+        nseg++;
+        PathHit ph;
+        ph.t = best_t;
+        ph.node = best;
+        ph.info = (r.best_mat & 0xFFFFFFu) | (B0 ? (draws << 24) : 0u);
+        *reinterpret_cast<uint4*>(P.hit + entry) = *reinterpret_cast<const uint4*>(&ph);
+      }
+      has = false;
+    }
+    {
+      const unsigned long long need = __ballot(!has);
+      if (need) {
+        if (w_next >= w_end && !exhausted) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(cursor, chunk);
+          base = __shfl(base, 0);
+          w_next = base;
+          w_end = min(base + chunk, n_live);
+          if (base >= n_live) { exhausted = true; w_end = w_next; }
+        }
+        const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
+        const uint32_t avail = w_end - w_next;
+        if (!has && rank < avail) {
+          entry = w_next + rank;
+          uint32_t id = entry;
+          uint32_t tries = 0;
+          if (B0) path_camera_ray(S, B, entry, r.wo, r.wd, r.time, tries);
+          else ray_load(ray_in + entry, r.wo, r.wd, r.time, id);
+          const bool dead = !B0 && id == CHIP_DEAD_ID;
+          if (dead) *reinterpret_cast<uint4*>(P.hit + entry) = make_uint4(0u, 0u, NREF_DEAD, 0u);
+          r.o = r.wo; r.d = r.wd;
+          const bool ordinary = ray_set_inv<true>(r);
+          const bool to_literal = !dead && (B.reference_order || !ordinary);
+          const unsigned long long ml = __ballot(to_literal);
+          if (ml) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)ml) - 1u;
+            uint32_t lbase = 0;
+            if (lane == leader) lbase = atomicAdd(&ctr[CHIP_CTR_LIT], (uint32_t)__popcll(ml));
+            lbase = __shfl(lbase, leader);
+            if (to_literal) P.q_lit[lbase + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull))] = entry;
+          }
+          if (!to_literal && !dead) {
+            r.capf = INFINITY;
+            if (B0) draws = tries;
+            best_t = INFINITY;
+            best = NREF_NONE;
+            node = root;
+            st.sp = 0;
+            has = true;
+          }
+        }
+        w_next += min((uint32_t)__popcll(need), avail);
+      }
+    }
+    if (!__any(has) && exhausted) break;
+    if (has) traverse_small<true>(S, C, node, r, 0.001, best_t, best, st, cnt, (exhausted && w_next >= w_end) ? 0 : (B0 ? CHIP_REFILL_THRESH_B0 : CHIP_REFILL_THRESH));
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt.bvh += __shfl_down(cnt.bvh, off);
+    cnt.prim += __shfl_down(cnt.prim, off);
+    nseg += __shfl_down(nseg, off);
+  }
+  if (lane == 0 && nseg) {
+    atomicAdd(&P.stats[0], (unsigned long long)nseg);
+    atomicAdd(&P.stats[1], (unsigned long long)cnt.bvh);
+    atomicAdd(&P.stats[2], (unsigned long long)cnt.prim);
+  }
+}
+
 // One hit of one path: Material::emitted / scatter / scattering_pdf of material kind KIND plus the PDF
 // branch of camera.rs:278-305.  The segment's ray (ro, rd, rtime) and closest hit (ph) come from the
 // caller.  Returns true with the next ray and the bounce's map x -> clamp(xw x, klo, khi) if the material

@@ -723,3 +723,25 @@ def test_progressive_blocks_end_in_the_frame(pkg, gpu, tmp_path):
 
     sc.render_frame_blocks(on_rect, block_size=16, passes=2, seed=6, rect=rect, flags=pkg.bindings.RENDER_QUANTISE_255)
     assert np.array_equal(got_r, want_r)
+
+
+@pytest.mark.gpu
+def test_compact_sphere_form_equals_general_form(pkg, gpu, monkeypatch):
+    """Small scenes of bare spheres run a form of the traversal kernel with 11-bit node references and 4-byte stack
+    words (k_extend_small); a ray whose descent needs more stack than LDS holds is handed to the literal pass.  The
+    image must not depend on which form ran or on how many rays took the hand-over: the closest hit of a ray is the
+    same however it is found (ties by the reference's order)."""
+    monkeypatch.delenv("CHIP_NO_SMALL_FORM", raising=False)
+    monkeypatch.delenv("CHIP_SMALL_STACK", raising=False)
+    sc = pkg.scenes.build(gpu, "random_spheres", width=160, spp=16, depth=12)
+    want, _, st0 = sc.render_frame(seed=5)
+    monkeypatch.setenv("CHIP_NO_SMALL_FORM", "1")
+    general, _, st1 = sc.render_frame(seed=5)
+    monkeypatch.delenv("CHIP_NO_SMALL_FORM")
+    assert np.array_equal(want, general)
+    assert st0["segments"] == st1["segments"] and st0["bvh_visits"] != 0
+    # four stack words per lane: most descents overflow and go through the literal pass
+    monkeypatch.setenv("CHIP_SMALL_STACK", "4")
+    tight, _, st2 = sc.render_frame(seed=5)
+    assert np.array_equal(want, tight)
+    assert st2["segments"] == st0["segments"]

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
-enum Kind { FMA32, FMA64, ADD64, IADD, MINU, CNDMASK, MAX3, PKFMA, MAX32, CMP32, AND32, ANDOR, MUL64, MADU24, CVT, ADD32, MUL32, LSHL };
+enum Kind { FMA32, FMA64, ADD64, IADD, MINU, CNDMASK, MAX3, PKFMA, MAX32, CMP32, AND32, ANDOR, MUL64, MADU24, CVT, ADD32, MUL32, LSHL, MAD64, MULHI, MULLO, RCP32, SQRT64, RCP64 };
 template <int K>
 __global__ void __launch_bounds__(1024) k_loop(double* out, int iters) {
   float f[8]; double d[8]; unsigned u[8];
@@ -35,6 +35,12 @@ __global__ void __launch_bounds__(1024) k_loop(double* out, int iters) {
       if (K == ADD32) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[j]) : "v"(fc));
       if (K == MUL32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[j]) : "v"(fm));
       if (K == LSHL) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(u[j]));
+      if (K == MAD64) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d[j]) : "v"(u[j]), "v"(u[(j + 1) & 7]) : "vcc");
+      if (K == MULHI) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+      if (K == MULLO) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) & 7]));
+      if (K == RCP32) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[j]));
+      if (K == SQRT64) asm volatile("v_sqrt_f64 %0, %0" : "+v"(d[j]));
+      if (K == RCP64) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[j]));
       if (K == PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(d[j]) : "v"(dm));
     }
   }
@@ -85,5 +91,11 @@ int main() {
   run<MUL64>("v_mul_f64", out);
   run<MADU24>("v_mad_u32_u24", out);
   run<CVT>("v_cvt_f32_f64", out);
+  run<MAD64>("v_mad_u64_u32", out);
+  run<MULHI>("v_mul_hi_u32", out);
+  run<MULLO>("v_mul_lo_u32", out);
+  run<RCP32>("v_rcp_f32", out);
+  run<SQRT64>("v_sqrt_f64", out);
+  run<RCP64>("v_rcp_f64", out);
   return 0;
 }
