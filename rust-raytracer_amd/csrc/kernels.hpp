@@ -1443,6 +1443,35 @@ __device__ inline void quad_load(const void* base, uint32_t slot, uint32_t lane,
   }
   __builtin_amdgcn_wave_barrier();
 }
+// The same in two steps, for a caller that has work to do while the loads are in flight: the loads ...
+template <int STRIDE, int NCH>
+__device__ inline void quad_load_issue(const void* base, uint32_t slot, uint32_t lane, uint4 (&v)[4]) {
+  const uint32_t c = lane & 3;
+  uint32_t s[4] = {quad_bcast<0>(slot), quad_bcast<1>(slot), quad_bcast<2>(slot), quad_bcast<3>(slot)};
+  // (each load under its own condition, as in quad_load: measured faster than loads without branches, and the
+  // branches keep the compiler from moving the loads down to their first use)
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    v[j] = make_uint4(0, 0, 0, 0);
+    if (s[j] != CHIP_NO_SLOT && (NCH == 4 || c < NCH))
+      v[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + (size_t)s[j] * STRIDE + c * 16);
+  }
+}
+// ... and the exchange through the staging buffer that hands every lane the chunks of its own record.
+template <int NCH>
+__device__ inline void quad_load_finish(const uint4 (&v)[4], uint32_t lane, uint4* stage, QuadRecord& r) {
+  const uint32_t c = lane & 3, q = lane >> 2;
+#pragma unroll
+  for (int j = 0; j < 4; j++) stage[xpose_at(16u * j + q) + c] = v[j];
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t own = xpose_at(16u * c + q);
+#pragma unroll
+  for (int k = 0; k < NCH; k++) {
+    const uint4 t = stage[own + k];
+    r.w[k][0] = t.x; r.w[k][1] = t.y; r.w[k][2] = t.z; r.w[k][3] = t.w;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
 // Stores the first NCH chunks of the record of every lane whose slot is not CHIP_NO_SLOT.
 template <int STRIDE, int NCH>
 __device__ inline void quad_store(void* base, uint32_t slot, uint32_t lane, uint4* stage, const QuadRecord& r) {
@@ -1794,10 +1823,9 @@ __device__ inline void sm_push(SmallStack& s, uint32_t key) {
   s.sp += key != 0xFFFFFFFFu ? 1 : 0;
 }
 __device__ inline void sm_room(SmallStack& s) {
-  if (s.sp > s.lds_cap - 3) {
-    s.sp = s.lds_cap - 3;
-    s.overflow = 1;
-  }
+  const int lim = s.lds_cap - 3;
+  s.overflow |= s.sp > lim ? 1u : 0u;
+  s.sp = min(s.sp, lim);
 }
 __device__ inline uint32_t sm_pop(SmallStack& s, float capf) {
   for (;;) {
@@ -1841,24 +1869,30 @@ __device__ void traverse_small(const DScene& S, const NodeCache& C, uint32_t& no
 #define CHIP_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
       CHIP_CSWAP(0, 1) CHIP_CSWAP(2, 3) CHIP_CSWAP(0, 2) CHIP_CSWAP(1, 3) CHIP_CSWAP(1, 2)
 #undef CHIP_CSWAP
-      if (key[0] == 0xFFFFFFFFu) {
-        node = sm_pop(st, r.capf);
-      } else {
-        sm_room(st);
-        if (__any(key[2] != 0xFFFFFFFFu)) {  // three or four children in reach: rare enough to be worth the branch
-          sm_push(st, key[3]);
-          sm_push(st, key[2]);
-        }
-        sm_push(st, key[1]);
-        node = key[0] & CHIP_SM_NONE;
+      // (a node without a child in reach has four all-ones keys: the pushes keep nothing and the next node is "none")
+      sm_room(st);
+      if (__any(key[2] != 0xFFFFFFFFu)) {  // three or four children in reach: rare enough to be worth the branch
+        sm_push(st, key[3]);
+        sm_push(st, key[2]);
       }
+      sm_push(st, key[1]);
+      node = key[0] & CHIP_SM_NONE;
+      if (node == CHIP_SM_NONE) node = sm_pop(st, r.capf);
     }
     if (node == CHIP_SM_NONE) break;
     if (node >= CHIP_SM_SPHERE) {  // (a lane still at a culling node sits this round out)
       const uint32_t idx = node & 0x3FFu;
       cnt.prim++;
       SphereRec sp;
-      load_sphere<true>(S, C, idx, sp);
+      {  // every sphere of such a scene is in LDS: no "cached?" test, no path to memory
+        const uint32_t i = C.sph_off + idx;
+        const uint4 a = lds_read4(i), b = lds_read4(i + C.cap_sph), c = lds_read4(i + 2 * C.cap_sph), d = lds_read4(i + 3 * C.cap_sph);
+        sp.c[0] = u2d(a.x, a.y); sp.c[1] = u2d(a.z, a.w);
+        sp.c[2] = u2d(b.x, b.y); sp.dc[0] = u2d(b.z, b.w);
+        sp.dc[1] = u2d(c.x, c.y); sp.dc[2] = u2d(c.z, c.w);
+        sp.r = u2d(d.x, d.y);
+        sp.mat = d.z;
+      }
       double t;
       if (sphere_hit_incl(sp, r, tmin, best_t, t)) {
         const nref_t ref = NREF(NK_SPHERE, idx);
@@ -2232,9 +2266,21 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
       }                                                                                                          \
       float xw[3] = {0.f, 0.f, 0.f}, klo = 0.f, khi = 0.f;                                                       \
       bool cont = false;                                                                                         \
+      /* The lean forms have registers to spare: their radiance-map loads are issued before the material code and  \
+         travel while it chases the hit's sphere and material records (one memory round trip less per trip).  The \
+         other forms load the map after the material code, which is where their registers are scarce. */         \
+      constexpr bool EARLY_MAP = LEAN && FAST && !B0;                                                            \
+      uint4 mapv[4];                                                                                             \
+      if (EARLY_MAP) quad_load_issue<(int)sizeof(PathMap), 3>(P.st[bounce & 1], entry, lane, mapv);              \
       if (valid) cont = shade_hit<KIND, FAST, LEAN, EXT, PLAIN>(S, B, bounce, id, ph, ro, rd, rtime, xw, klo, khi, no, nd); \
-      Affine f;  /* loaded after the material code, which is where the registers are scarce */                  \
-      quad_load_map<B0>(P, entry, lane, bounce, stage, f, id);                                                   \
+      Affine f;                                                                                                  \
+      if (EARLY_MAP) {                                                                                           \
+        QuadRecord qm;                                                                                           \
+        quad_load_finish<3>(mapv, lane, stage, qm);                                                              \
+        affine_unpack(qm, f, id);                                                                                \
+      } else {                                                                                                   \
+        quad_load_map<B0>(P, entry, lane, bounce, stage, f, id);                                                 \
+      }                                                                                                          \
       if (valid) {                                                                                               \
         if (cont) {                                                                                              \
           affine_compose(f, xw, klo, khi);                                                                       \
