@@ -381,7 +381,7 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
     // cache they cost; the sphere scenes' trees are shallow
     p.cd.stack_entries = (feat & TF_NO_QUADROT) ? 10 : 8;
     if (const char* es = getenv("CHIP_LDS_STACK")) { int v = atoi(es); if (v >= 2 && v <= 16) p.cd.stack_entries = (uint32_t)v; }
-    const uint32_t stack_bytes = p.cd.stack_entries * 8 * p.block;
+    const uint32_t stack_bytes = (p.cd.stack_entries + 1) * 8 * p.block;  // (+ the spare entry of st_push_sel)
     const uint32_t node_bytes = 16 * CHIP_WNODE_U4, sphere_bytes = 64;
     uint32_t budget = kLdsBytes - stack_bytes;
     p.cd.n_bvh = (uint32_t)std::min<size_t>(s->flat.n_wide, budget / node_bytes);
@@ -406,7 +406,7 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
     p.block = CHIP_BLOCK;
     p.cd.stack_entries = CHIP_STACK_LDS;
     p.cd.n_bvh = p.cd.n_sph = 0;
-    p.lds_bytes = CHIP_STACK_LDS * 8 * CHIP_BLOCK;
+    p.lds_bytes = (CHIP_STACK_LDS + 1) * 8 * CHIP_BLOCK;
   }
   return p;
 }
@@ -431,7 +431,7 @@ static int launch_extend_b(const DeviceState& D, const PathPool& P, const Extend
   uint32_t lds_bytes = p.lds_bytes;
   if (!CACHE && lit_pass && n_live_upper <= 1u) {
     threads = 64u;
-    lds_bytes = p.cd.stack_entries * 8u * threads;
+    lds_bytes = (p.cd.stack_entries + 1u) * 8u * threads;
   }
   hipLaunchKernelGGL((k_extend<F, CACHE, ORD, B0>), dim3(blocks), dim3(threads), lds_bytes, st, D.dscene, P, B, bounce, p.cd, lit_pass);
   return 0;

@@ -312,6 +312,27 @@ __device__ inline void st_push(TravStack& s, uint32_t v, float t = 0.0f) {
   } else { s.overflow = 1; return; }
   s.sp++;
 }
+// Push without a branch in the common case, for the ordered descent's deferred children: the entry is written
+// whether or not the lane pushes (`take`), into the next free LDS entry, or into the spare entry behind the LDS part
+// (index lds_cap: the kernels allocate one entry more than lds_cap) once the lane is past it, and the stack pointer
+// moves only for a lane that pushes.  The spill slab is written under a wave-uniform branch that is rarely taken.
+__device__ inline void st_push_sel(TravStack& s, uint32_t v, float t, bool take) {
+  u32x2_t e;
+  e.x = v; e.y = __float_as_uint(t);
+  *(lds_u2_t)((lds_b_t)s.lds + __umul24((uint32_t)min(s.sp, s.lds_cap), s.stride8)) = e;
+  if (__any(take && s.sp >= s.lds_cap)) {
+    if (take && s.sp >= s.lds_cap) {
+      if (s.sp < s.lds_cap + CHIP_STACK_OVF) {
+        s.ovf[2 * (s.sp - s.lds_cap)] = v;
+        s.ovf[2 * (s.sp - s.lds_cap) + 1] = __float_as_uint(t);
+      } else {
+        s.overflow = 1;
+        take = false;
+      }
+    }
+  }
+  s.sp += take ? 1 : 0;
+}
 __device__ inline uint32_t st_pop_raw(TravStack& s, int base, bool with_t) {
   if (s.sp <= base) return NREF_NONE;
   s.sp--;
@@ -458,7 +479,7 @@ __device__ inline bool ray_set_cull(TravRay& r) {
     r.c_n[a] = fmaf(-fabsf(pn), 2.3841858e-07f, pn);
     r.c_f[a] = fmaf(fabsf(pf), 2.3841858e-07f, pf);
     r.far16[a] = invf > 0.0f ? 0u : 16u;
-    ok = ok && fabsf(invf) > 1.0e-18f && fabsf(invf) < 1.0e18f;  // (false for NaN)
+    ok = ok & (fabsf(invf) > 1.0e-18f) & (fabsf(invf) < 1.0e18f);  // (false for NaN; no short-circuit branches)
   }
   return ok;
 }
@@ -780,16 +801,14 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
         CHIP_CSWAP(0, 1) CHIP_CSWAP(2, 3) CHIP_CSWAP(0, 2) CHIP_CSWAP(1, 3) CHIP_CSWAP(1, 2)
 #undef CHIP_CSWAP
 #define CHIP_CHILD(kk) (((kk) & 2u) ? (((kk) & 1u) ? n.child[3] : n.child[2]) : (((kk) & 1u) ? n.child[1] : n.child[0]))
-        if (key[0] == 0xFFFFFFFFu) {
-          node = st_pop<true>(st, base, r.capf);
-        } else {
-          if (__any(key[2] != 0xFFFFFFFFu)) {  // three or four children in reach: rare enough to be worth the branch
-            if (key[3] != 0xFFFFFFFFu) st_push<true>(st, CHIP_CHILD(key[3]), __uint_as_float(key[3] & ~3u));
-            if (key[2] != 0xFFFFFFFFu) st_push<true>(st, CHIP_CHILD(key[2]), __uint_as_float(key[2] & ~3u));
-          }
-          if (key[1] != 0xFFFFFFFFu) st_push<true>(st, CHIP_CHILD(key[1]), __uint_as_float(key[1] & ~3u));
-          node = CHIP_CHILD(key[0]);
+        // (a node without a child in reach has four all-ones keys: the pushes keep nothing and the node is popped)
+        if (__any(key[2] != 0xFFFFFFFFu)) {  // three or four children in reach: rare enough to be worth the branch
+          st_push_sel(st, CHIP_CHILD(key[3]), __uint_as_float(key[3] & ~3u), key[3] != 0xFFFFFFFFu);
+          st_push_sel(st, CHIP_CHILD(key[2]), __uint_as_float(key[2] & ~3u), key[2] != 0xFFFFFFFFu);
         }
+        st_push_sel(st, CHIP_CHILD(key[1]), __uint_as_float(key[1] & ~3u), key[1] != 0xFFFFFFFFu);
+        node = CHIP_CHILD(key[0]);
+        if (key[0] == 0xFFFFFFFFu) node = st_pop<true>(st, base, r.capf);
 #undef CHIP_CHILD
       }
     } else {
@@ -1651,7 +1670,7 @@ __host__ __device__ constexpr int extend_min_waves(uint32_t F, bool CACHE) {
 template <uint32_t F, bool CACHE, bool ORD, bool B0>
 __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CACHE)) k_extend(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg, CacheDesc cd, uint32_t lit_pass) {
   const uint32_t bounce = B0 ? 0u : bounce_arg;
-  // LDS layout: [7 x n_bvh uint4: culling nodes][4 x n_sph uint4: spheres][stack_entries x blockDim (value, distance) pairs]
+  // LDS layout: [7 x n_bvh uint4: culling nodes][4 x n_sph uint4: spheres][(stack_entries + 1) x blockDim (value, distance) pairs]
   const NodeCache C{0u, (uint32_t)CHIP_WNODE_U4 * cd.n_bvh, cd.n_bvh, cd.n_sph, cd.n_bvh, cd.n_sph};
   uint2* lds_stack = reinterpret_cast<uint2*>(g_lds + (CHIP_WNODE_U4 * cd.n_bvh + 4u * cd.n_sph));
   uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
@@ -2372,7 +2391,7 @@ struct DHitOut {
 template <uint32_t F>
 __global__ void __launch_bounds__(CHIP_BLOCK) k_trace_rays(DScene S, PathPool P, uint32_t seed_lo, uint32_t seed_hi, uint32_t n,
                                                            const double* o, const double* d, const double* tm, DHitOut* out) {
-  __shared__ uint2 lds_stack[CHIP_STACK_LDS * CHIP_BLOCK];
+  __shared__ uint2 lds_stack[(CHIP_STACK_LDS + 1) * CHIP_BLOCK];  // (+ the spare entry of st_push_sel)
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   TravStack st;
   st.lds = (lds_u2_t)lds_stack + threadIdx.x;
