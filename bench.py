@@ -66,8 +66,11 @@ def load_profile():
     """The committed PMC-derived figures; None (and the reason) when absent or taken on other kernel sources."""
     if not os.path.exists(PROFILE_JSON):
         return None, "no profile file"
-    with open(PROFILE_JSON) as fh:
-        prof = json.load(fh)
+    try:
+        with open(PROFILE_JSON) as fh:
+            prof = json.load(fh)
+    except ValueError:
+        return None, "profile file is not valid JSON"
     if prof.get("kernel_source_sha256_16") != kernel_source_hash():
         return prof, "profile was taken on other kernel sources (stale)"
     return prof, None
@@ -248,7 +251,7 @@ def main():
         usable = bool(ops_per_seg) and not prof_note and default_workload
         achieved = ops_per_seg * seg / (ms_trace * 1e-3) / 1e12 if (usable and ms_trace > 0) else None
         roofline = {
-            "kernel": "k_extend<0, true, true, *> (ordered closest-hit traversal: f32 culling of 4-wide nodes, f64 sphere tests, scene tables in LDS)",
+            "kernel": "k_extend_small<*> (ordered closest-hit traversal, compact form: f32 culling of 4-wide nodes, f64 sphere tests, scene tables in LDS)",
             "bound": "valu",
             "achieved": achieved,
             "peak": VALU_PEAK_TLANEOPS,

@@ -28,5 +28,7 @@ pass s5 mix SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ
 { timeout -k 5 200 "$ROOT/tools/micro/valu_clock" > "$OUT/valu_issue_cost.txt" 2> "$OUT/valu_issue_cost.err" || { echo "valu_clock failed"; exit 1; }; } &&
 python3 "$ROOT/tools/pmc_summary.py" "$OUT/s2" > "$OUT/pmc_s2_summary.txt" &&
 python3 "$ROOT/tools/pmc_summary.py" "$OUT/s5" > "$OUT/pmc_s5_summary.txt" &&
-python3 "$ROOT/tools/make_roofline_profile.py" "$OUT" "$GIT" > "$OUT/roofline_profile.json" && cat "$OUT/roofline_profile.json"
+python3 "$ROOT/tools/make_roofline_profile.py" "$OUT" "$GIT" > "$OUT/roofline_profile.json.tmp" && mv "$OUT/roofline_profile.json.tmp" "$OUT/roofline_profile.json" && cat "$OUT/roofline_profile.json"
+RC=$?
 rm -rf "$OUT"/s2/sq "$OUT"/s2/fetch "$OUT"/s2/write "$OUT"/s2/mix "$OUT"/s5/sq "$OUT"/s5/fetch "$OUT"/s5/write "$OUT"/s5/mix
+exit $RC

@@ -20,12 +20,12 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def counters(path, kernel_prefix):
-    """Sums over every instantiation whose name starts with kernel_prefix: {counter: (sum, dispatches)}."""
+def counters(path, kernel_prefixes):
+    """Sums over every instantiation whose name starts with one of kernel_prefixes: {counter: (sum, dispatches)}."""
     acc = {}
     for line in open(path):
         m = re.match(r"(\S.*?)\s+(\S+)\s+sum=(\S+) dispatches=(\d+)", line)
-        if not m or not m.group(1).startswith(kernel_prefix):
+        if not m or not m.group(1).startswith(tuple(kernel_prefixes)):
             continue
         s, n = acc.get(m.group(2), (0.0, 0))
         acc[m.group(2)] = (s + float(m.group(3)), n + int(m.group(4)))
@@ -99,11 +99,11 @@ def main():
     b = last_json(os.path.join(d, "s2", "sq.log"))
     seg2 = b["roofline"]["segments_per_path"] * b["config"]["path_samples_per_step"] * b["steps"]
     cost = issue_costs(os.path.join(d, "valu_issue_cost.txt"))
-    s2 = figures(counters(os.path.join(d, "pmc_s2_summary.txt"), "k_extend<0u, true, true"), seg2, cost)
+    s2 = figures(counters(os.path.join(d, "pmc_s2_summary.txt"), ("k_extend_small<", "k_extend<0u, true, true")), seg2, cost)
     s2["workload"] = b["config"]["workload"] + " (one frame under rocprofv3 --pmc, kernels serialised)"
     l = last_json(os.path.join(d, "s5", "sq.log"))
     seg5 = 2 * l["segments_per_path"] * 1920 * 1080 * l["spp"]  # run_configs renders the frame twice
-    s5 = figures(counters(os.path.join(d, "pmc_s5_summary.txt"), "k_extend<35u, true, true"), seg5, cost)
+    s5 = figures(counters(os.path.join(d, "pmc_s5_summary.txt"), ("k_extend<35u, true, true",)), seg5, cost)
     s5["workload"] = l["config"] + f", {l['spp']} spp, two renders under rocprofv3 --pmc"
     out = {
         "git": git,
