@@ -479,7 +479,7 @@ __device__ inline bool ray_set_cull(TravRay& r) {
     r.c_n[a] = fmaf(-fabsf(pn), 2.3841858e-07f, pn);
     r.c_f[a] = fmaf(fabsf(pf), 2.3841858e-07f, pf);
     r.far16[a] = invf > 0.0f ? 0u : 16u;
-    ok = ok & (fabsf(invf) > 1.0e-18f) & (fabsf(invf) < 1.0e18f);  // (false for NaN; no short-circuit branches)
+    ok = ((int)ok & (int)(fabsf(invf) > 1.0e-18f) & (int)(fabsf(invf) < 1.0e18f)) != 0;  // (false for NaN; no short-circuit branches)
   }
   return ok;
 }
