@@ -1761,7 +1761,11 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
           // the culling form is computed first: it also tells whether the ordered traversal can take the ray
           r.o = r.wo; r.d = r.wd;
           const bool ordinary = ray_set_inv<ORD>(r);
+#ifdef CHIP_TEST_HAND_OVER  // (test build: every CHIP_TEST_HAND_OVER-th ray takes the hand-over to the literal traversal)
+          const bool to_literal = !dead && ORD && (B.reference_order || !ordinary || entry % CHIP_TEST_HAND_OVER == 0u);
+#else
           const bool to_literal = !dead && ORD && (B.reference_order || !ordinary);
+#endif
           if (ORD) {  // the literal queue takes these rays (appended with one atomic per wave)
             const unsigned long long ml = __ballot(to_literal);
             if (ml) {
@@ -2014,7 +2018,11 @@ __global__ void __launch_bounds__(extend_block(0, true), extend_min_waves(0, tru
           if (dead) *reinterpret_cast<uint4*>(P.hit + entry) = make_uint4(0u, 0u, NREF_DEAD, 0u);
           r.o = r.wo; r.d = r.wd;
           const bool ordinary = ray_set_inv<true>(r);
+#ifdef CHIP_TEST_HAND_OVER
+          const bool to_literal = !dead && (B.reference_order || !ordinary || entry % CHIP_TEST_HAND_OVER == 0u);
+#else
           const bool to_literal = !dead && (B.reference_order || !ordinary);
+#endif
           const unsigned long long ml = __ballot(to_literal);
           if (ml) {
             const uint32_t leader = (uint32_t)__ffsll((long long)ml) - 1u;

@@ -745,3 +745,29 @@ def test_compact_sphere_form_equals_general_form(pkg, gpu, monkeypatch):
     tight, _, st2 = sc.render_frame(seed=5)
     assert np.array_equal(want, tight)
     assert st2["segments"] == st0["segments"]
+
+
+@pytest.mark.gpu
+def test_literal_hand_over_of_every_fifth_ray(pkg, gpu):
+    """The ordered traversal hands a ray it cannot take (a zero direction component, a descent deeper than the compact
+    form's stack) to the literal traversal, which runs as a pass of its own after it: a ray or two per frame in the
+    book scenes.  The test build of the library (csrc/Makefile: libcaustic_hip_handover.so) hands every fifth ray
+    over, in both forms of the kernel (the LDS-resident one of the early bounces and the plain one of the short late
+    queues) and at bounce 0 as well: the image and the segment count must be those of the product library, since the
+    closest hit of a ray does not depend on the order in which the tree was searched (ties by the reference's
+    order)."""
+    import ctypes as C
+    import os
+
+    path = os.path.join(os.path.dirname(pkg.bindings.GPU_LIB_PATH), "libcaustic_hip_handover.so")
+    assert os.path.exists(path), "build it with make -C rust-raytracer_amd/csrc"
+    forced = pkg.bindings.Backend(C.CDLL(path), "chip_", "libcaustic_hip_handover")
+    for name, kw in (("random_spheres", dict(width=160, spp=16, depth=12)), ("random_spheres", dict(width=48, spp=4, depth=8)),
+                     ("three_spheres", dict(width=200, spp=9, depth=10)), ("checkered_spheres", dict(width=64, spp=4, depth=10))):
+        a = pkg.scenes.build(gpu, name, **kw)
+        b = pkg.scenes.build(forced, name, **kw)
+        want, _, st_a = a.render_frame(seed=11)
+        got, _, st_b = b.render_frame(seed=11)
+        assert np.array_equal(want, got), (name, kw)
+        assert st_a["segments"] == st_b["segments"]
+
