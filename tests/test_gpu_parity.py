@@ -362,6 +362,36 @@ def test_full_size_frame_properties(pkg, gpu, monkeypatch):
     assert np.allclose(r0 + r1, a, rtol=1e-5, atol=1e-5)
 
 
+def test_headline_frame_against_oracle_and_rank_shares(pkg, gpu, oracle):
+    """One frame of the benchmark's configuration in full (RTIOW final scene, 1920 x 1080, 1024 strata, depth 50: 2.1 G
+    paths).  (i) Four rectangles of it (centre, a corner, the horizon with the small spheres, the big glass sphere)
+    against the oracle's render of the same rectangles with the same seed: both follow the same Philox stream, so a
+    value differs only by f32 summation and by the rare path whose f32 shading arithmetic took another branch than the
+    oracle's f64 (one path is a thousandth of a pixel).  Measured: median 3e-6, 99th percentile 3e-5, largest 1.3e-4
+    relative, rectangle means 4e-7; bars: 99 % within 2e-4, all within 5e-3, means within 2e-5.  (ii) The frame is
+    the sum of the eight rank shares the 8-GPU job renders (strata r, r + 8, ...) to f32 addition order (measured
+    2e-5), segment for segment."""
+    sg = pkg.scenes.build(gpu, "random_spheres", width=1920, spp=1024, depth=50)
+    so = pkg.scenes.build(oracle, "random_spheres", width=1920, spp=1024, depth=50)
+    full, _, st = sg.render_frame(seed=4)
+    assert st["paths"] == 1920 * 1080 * 1024
+    assert np.isfinite(full).all() and full.min() >= 0.0
+    for rect in ((944, 976, 528, 552), (0, 32, 0, 24), (1200, 1232, 640, 664), (930, 962, 700, 724)):  # xmin, xmax, ymin, ymax
+        want, _, _ = so.render_frame(seed=4, rect=rect, sum_dtype=np.float64)
+        got = full[rect[2]:rect[3], rect[0]:rect[1]].astype(np.float64)
+        rel = np.abs(got - want) / (1.0 + np.abs(want))  # (the values are sums over the 1024 strata)
+        assert np.quantile(rel, 0.99) <= 2e-4 and rel.max() <= 5e-3, (rect, float(np.quantile(rel, 0.99)), float(rel.max()))
+        assert abs(got.mean() - want.mean()) <= 2e-5 * want.mean(), (rect, got.mean(), want.mean())
+    acc = np.zeros(full.shape, dtype=np.float64)
+    segments = 0
+    for r in range(8):
+        part, _, sr = sg.render_frame(seed=4, stratum_offset=r, stratum_stride=8)
+        acc += part
+        segments += sr["segments"]
+    assert segments == st["segments"]
+    assert np.allclose(acc, full, rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("variant", ["bare_quad", "bare_sphere", "empty_group", "group_with_unsampled_members", "disc", "frustum"])
 def test_light_list_shapes(pkg, gpu, oracle, variant):
     """SceneData.lights in every shape camera.rs:278-305 can meet: a node that is not a Group (its own pdf_value /
