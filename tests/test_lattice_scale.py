@@ -114,14 +114,44 @@ def test_million_instance_same_seed_render_equals_oracle(pkg, lattice):
     assert abs(mean_g - mean_o) <= 0.02 * mean_o
 
 
-def test_million_instance_same_seed_render_equals_oracle_at_depth_6(pkg, lattice):
-    """(Last in this module: it replaces the camera of the shared scenes.)"""
-    sg, so = lattice
+def _set_camera(scenes, spp, depth):
     d = 1.6 * N
-    for sc in (sg, so):
-        sc.set_camera(image_width=1920, samples_per_pixel=4, max_depth=6, aspect_ratio=16.0 / 9.0, vertical_fov=40.0, look_from=(d, 0.9 * N, d),
+    for sc in scenes:
+        sc.set_camera(image_width=1920, samples_per_pixel=spp, max_depth=depth, aspect_ratio=16.0 / 9.0, vertical_fov=40.0, look_from=(d, 0.9 * N, d),
                       look_at=(0.0, 0.45 * N, 0.0), up=(0.0, 1.0, 0.0), defocus_angle=0.0, background=(0.7, 0.8, 1.0))
         sc.commit()
+
+
+def test_million_instance_full_configuration(pkg, lattice):
+    """The configuration in full: 1920 x 1080, 256 strata, depth 50 (0.53 G paths).  (From here on the tests of this
+    module replace the camera of the shared scenes.)  A window of the frame against the oracle's same-seed render of
+    it: the paths that end up elsewhere on the two sides (see above) are each 1/256 of a pixel now.  And the frame is
+    the sum of the eight rank shares of the 8-GPU job, segment for segment."""
+    sg, so = lattice
+    _set_camera((sg, so), 256, 50)
+    full, _, st = sg.render_frame(seed=2)
+    assert st["paths"] == 1920 * 1080 * 256
+    assert np.isfinite(full).all() and full.min() >= 0.0
+    rect = (900, 996, 500, 564)
+    want, _, _ = so.render_frame(seed=2, rect=rect, sum_dtype=np.float64)
+    got = full[rect[2]:rect[3], rect[0]:rect[1]].astype(np.float64)
+    rel = np.abs(got - want) / (1.0 + np.abs(want))
+    # measured: median 1.3e-5, 90th percentile 3.8e-4, 99th 3.4e-3, largest 5.6e-2 relative; window mean 2.6e-6
+    assert np.median(rel) <= 2e-4 and np.quantile(rel, 0.99) <= 2e-2, (float(np.median(rel)), float(np.quantile(rel, 0.99)), float(rel.max()))
+    assert abs(got.mean() - want.mean()) <= 1e-4 * want.mean()
+    acc = np.zeros(full.shape, dtype=np.float64)
+    segments = 0
+    for r in range(8):
+        part, _, sr = sg.render_frame(seed=2, stratum_offset=r, stratum_stride=8)
+        acc += part
+        segments += sr["segments"]
+    assert segments == st["segments"]
+    assert np.allclose(acc, full, rtol=1e-4, atol=1e-3)
+
+
+def test_million_instance_same_seed_render_equals_oracle_at_depth_6(pkg, lattice):
+    sg, so = lattice
+    _set_camera((sg, so), 4, 6)
     seg_g, seg_o, bad, _, _ = _same_seed_window(pkg, sg, so)
     assert seg_g == seg_o
     assert bad < 2e-3
