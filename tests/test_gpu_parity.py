@@ -398,6 +398,25 @@ def _rect_stats(full, want, rect):
     return float(np.median(rel)), float(np.quantile(rel, 0.99)), float(rel.max()), float(abs(got.mean() - want.mean()) / want.mean())
 
 
+def test_reference_cli_configuration_against_oracle(pkg, gpu, oracle):
+    """The reference's own CPU-runnable case in full: the RTIOW final scene at 400 x 225, `samples_per_pixel` 10 (which
+    camera.rs:168-170 turns into 3 x 3 strata), depth 50.  Every value of the frame against the oracle's same-seed
+    frame, in the default mode (f32 shading arithmetic) and with the reference's f64 shading order."""
+    sg = pkg.scenes.build(gpu, "random_spheres", width=400, spp=10, depth=50)
+    so = pkg.scenes.build(oracle, "random_spheres", width=400, spp=10, depth=50)
+    assert sg.image_size() == (400, 225) and sg.sqrt_spp() == 3
+    want, _, sw = so.render_frame(seed=9, sum_dtype=np.float64)
+    for flags in (0, pkg.bindings.RENDER_EXACT_SHADING):
+        got, _, st = sg.render_frame(seed=9, flags=flags)
+        assert st["paths"] == sw["paths"] == 400 * 225 * 9
+        med, p99, worst, mean = _rect_stats(got, want, (0, 400, 0, 225))
+        if flags:  # measured: the oracle's segments to the last one, values to 1.8e-7 relative (f32 sums)
+            assert st["segments"] == sw["segments"] and worst <= 2e-6, (st["segments"], sw["segments"], worst)
+        else:      # measured: 8 of 2 069 429 segments apart, 99th percentile 1e-7, one value 1.5e-2, frame mean 1e-8
+            assert abs(st["segments"] - sw["segments"]) <= 1e-4 * sw["segments"]
+            assert p99 <= 1e-5 and worst <= 0.2 and mean <= 1e-6, (med, p99, worst, mean)
+
+
 def test_cornell_full_configuration_against_oracle(pkg, gpu, oracle):
     """The Cornell-box configuration in full (600 x 600, 4096 strata, depth 50: 1.5 G paths with light and mixture-PDF
     sampling): three rectangles (the glass sphere, the light's edge, a wall corner) against the oracle's same-seed
