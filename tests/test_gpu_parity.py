@@ -370,14 +370,18 @@ def test_headline_frame_against_oracle_and_rank_shares(pkg, gpu, oracle):
     oracle's f64 (one path is a thousandth of a pixel).  Measured: median 3e-6, 99th percentile 3e-5, largest 1.3e-4
     relative, rectangle means 4e-7; bars: 99 % within 2e-4, all within 5e-3, means within 2e-5.  (ii) The frame is
     the sum of the eight rank shares the 8-GPU job renders (strata r, r + 8, ...) to f32 addition order (measured
-    2e-5), segment for segment."""
+    2e-5), segment for segment.  (iii) The same rectangles rendered with the reference's f64 shading order have the
+    oracle's segments to the last one (10 M in all) and its values to 1e-5 (f32 sums of 1024 terms)."""
     sg = pkg.scenes.build(gpu, "random_spheres", width=1920, spp=1024, depth=50)
     so = pkg.scenes.build(oracle, "random_spheres", width=1920, spp=1024, depth=50)
     full, _, st = sg.render_frame(seed=4)
     assert st["paths"] == 1920 * 1080 * 1024
     assert np.isfinite(full).all() and full.min() >= 0.0
     for rect in ((944, 976, 528, 552), (0, 32, 0, 24), (1200, 1232, 640, 664), (930, 962, 700, 724)):  # xmin, xmax, ymin, ymax
-        want, _, _ = so.render_frame(seed=4, rect=rect, sum_dtype=np.float64)
+        want, _, sw = so.render_frame(seed=4, rect=rect, sum_dtype=np.float64)
+        exact, _, se = sg.render_frame(seed=4, rect=rect, flags=pkg.bindings.RENDER_EXACT_SHADING)
+        rel = np.abs(exact.astype(np.float64) - want) / (1.0 + np.abs(want))
+        assert se["segments"] == sw["segments"] and rel.max() <= 5e-5, (rect, se["segments"], sw["segments"], float(rel.max()))
         got = full[rect[2]:rect[3], rect[0]:rect[1]].astype(np.float64)
         rel = np.abs(got - want) / (1.0 + np.abs(want))  # (the values are sums over the 1024 strata)
         assert np.quantile(rel, 0.99) <= 2e-4 and rel.max() <= 5e-3, (rect, float(np.quantile(rel, 0.99)), float(rel.max()))
