@@ -433,7 +433,9 @@ def test_cornell_full_configuration_against_oracle(pkg, gpu, oracle):
     assert st["paths"] == 600 * 600 * 4096
     assert np.isfinite(full).all() and full.min() >= 0.0
     for rect in ((180, 196, 420, 432), (200, 216, 40, 52), (2, 18, 580, 592)):
-        want, _, _ = so.render_frame(seed=6, rect=rect, sum_dtype=np.float64)
+        want, _, sw = so.render_frame(seed=6, rect=rect, sum_dtype=np.float64)
+        _, _, sr = sg.render_frame(seed=6, rect=rect, flags=pkg.bindings.RENDER_EXACT_SHADING)
+        assert sr["segments"] == sw["segments"], (rect, sr["segments"], sw["segments"])  # the oracle's segments to the last one
         med, p99, worst, mean = _rect_stats(full, want, rect)
         assert p99 <= 2e-5 and worst <= 1e-3 and mean <= 5e-6, (rect, med, p99, worst, mean)
 
@@ -449,7 +451,9 @@ def test_next_week_rank_share_of_full_configuration_against_oracle(pkg, gpu, ora
     assert st["paths"] == 800 * 800 * 1250
     assert np.isfinite(share).all() and share.min() >= 0.0
     for rect in ((392, 404, 380, 390), (120, 132, 600, 610), (560, 572, 300, 310)):
-        want, _, _ = so.render_frame(seed=8, rect=rect, stratum_offset=3, stratum_stride=8, sum_dtype=np.float64)
+        want, _, sw = so.render_frame(seed=8, rect=rect, stratum_offset=3, stratum_stride=8, sum_dtype=np.float64)
+        _, _, sr = sg.render_frame(seed=8, rect=rect, stratum_offset=3, stratum_stride=8, flags=pkg.bindings.RENDER_EXACT_SHADING)
+        assert sr["segments"] == sw["segments"], (rect, sr["segments"], sw["segments"])  # the oracle's segments to the last one
         med, p99, worst, mean = _rect_stats(share, want, rect)
         assert p99 <= 2e-5 and worst <= 1e-3 and mean <= 5e-6, (rect, med, p99, worst, mean)
 
