@@ -155,3 +155,44 @@ def test_scene_builder_takes_a_scad_path(pkg, oracle, tmp_path):
     bad.write_text("nonsense(1);\n")
     with pytest.raises(Exception):
         pkg.scenes.build(oracle, str(bad))
+
+
+def test_nested_for_loops_emit_the_lattice_shape(scad, oracle, pkg):
+    """What the interpreter emits for nested `for` loops of `translate() sphere()` (modules.rs:139-163 `for`, :274
+    `translate`, mod.rs:190-194 the top-level hierarchy): one BoundingVolumeHierarchy over n^3 Translate(Group[Sphere])
+    chains.  The synthetic million-instance scene of the benchmark (scenes.scad_lattice) is built from records of that
+    shape; here the same shape comes out of the .scad reader, and equals the record-built scene box for box."""
+    n = 5
+    src = "for (i = [0:%d]) for (j = [0:%d]) for (k = [0:%d]) translate([i - 2, j - 2, k + 0.5]) sphere(r=0.3);" % (n, n, n)
+    sc, msgs = scad.run_openscad(src, oracle)
+    assert msgs == []
+    kinds, ids, boxes = sc.dump_tree()
+    names = [pkg.bindings.NODE_KIND_NAMES[int(k)] for k in kinds]
+    total = n ** 3
+    # (a hierarchy node over one member holds it as both children, bounding_volume_hierarchy.rs:27-28, so the walk meets
+    # a few chains twice: count distinct nodes)
+    for kind in ("sphere", "group", "translate"):
+        assert len({int(i) for i, nm in zip(ids, names) if nm == kind}) == total, kind
+    assert names[0] == "bvh" and set(names) == {"bvh", "sphere", "group", "translate"}
+    # every Translate is followed by its Group and that by its Sphere
+    for i, nm in enumerate(names):
+        if nm == "translate":
+            assert names[i + 1] == "group" and names[i + 2] == "sphere"
+    # the same lattice from constructor records (the benchmark scene's path): the reader swaps axes to (-x, z, y)
+    B = pkg.bindings
+    ref = oracle.new_scene()
+    mat = ref.lambertian_color(0.5, 0.5, 0.5)
+    members = []
+    for i in range(n):
+        for j in range(n):
+            for k in range(n):
+                s_ = ref.sphere((0.0, 0.0, 0.0), 0.3, mat)
+                members.append(ref.translate(ref.group([s_]), (-(i - 2.0), k + 0.5, j - 2.0)))
+    ref.set_world(ref.bvh(members))
+    ref.set_lights(None)
+    ref.set_camera(image_width=16, samples_per_pixel=1, max_depth=2)
+    ref.commit()
+    k2, _, b2 = ref.dump_tree()
+    assert np.array_equal(kinds, k2)
+    assert np.array_equal(boxes.view(np.uint64), b2.view(np.uint64))
+
