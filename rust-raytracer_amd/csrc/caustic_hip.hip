@@ -1694,26 +1694,31 @@ int64_t chip_check_culling_trees(chip_scene* s) {
   };
   std::vector<nref_t> ref_units, ord_units, work;
   // reference order: hierarchies by their two children, Groups by their child lists, instances by `child`
-  work.assign(1, F.root);
-  while (!work.empty()) {
-    const nref_t r = work.back();
-    work.pop_back();
-    if (r == NREF_NONE) continue;
-    const uint32_t k = NREF_KIND(r), i = NREF_INDEX(r);
-    if (is_unit(r)) { ref_units.push_back(r); continue; }
-    if (k == NK_BVH) {
-      if (i >= F.bvh.size()) return fail("reference node index out of range");
-      work.push_back(F.bvh[i].left);
-      if (F.bvh[i].right != F.bvh[i].left) work.push_back(F.bvh[i].right);  // a single member is held twice (bvh.rs:27-28)
-    } else if (k == NK_GROUP) {
-      for (uint32_t j = 0; j < F.groups[i].count; j++) work.push_back(F.gchild[F.groups[i].first + j]);
-    } else if (k == NK_TRANSLATE) work.push_back(F.translates[i].child);
-    else if (k == NK_ROTATE) work.push_back(F.rotates[i].child);
-    else if (k == NK_SCALE) work.push_back(F.scales[i].child);
-    else return fail("unexpected node kind in the reference-order structure");
-  }
+  std::vector<nref_t> rwork;
+  auto ref_walk = [&](nref_t start, std::vector<nref_t>& units) -> const char* {
+    rwork.assign(1, start);
+    while (!rwork.empty()) {
+      const nref_t r = rwork.back();
+      rwork.pop_back();
+      if (r == NREF_NONE) continue;
+      const uint32_t k = NREF_KIND(r), i = NREF_INDEX(r);
+      if (is_unit(r)) { units.push_back(r); continue; }
+      if (k == NK_BVH) {
+        if (i >= F.bvh.size()) return "reference node index out of range";
+        rwork.push_back(F.bvh[i].left);
+        if (F.bvh[i].right != F.bvh[i].left) rwork.push_back(F.bvh[i].right);  // a single member is held twice (bvh.rs:27-28)
+      } else if (k == NK_GROUP) {
+        for (uint32_t j = 0; j < F.groups[i].count; j++) rwork.push_back(F.gchild[F.groups[i].first + j]);
+      } else if (k == NK_TRANSLATE) rwork.push_back(F.translates[i].child);
+      else if (k == NK_ROTATE) rwork.push_back(F.rotates[i].child);
+      else if (k == NK_SCALE) rwork.push_back(F.scales[i].child);
+      else return "unexpected node kind in the reference-order structure";
+    }
+    return nullptr;
+  };
+  if (const char* why = ref_walk(F.root, ref_units)) return fail(why);
   // ordered traversal: culling nodes by their child words, instances by `ord_child` from the innermost instance of
-  // their run (enter_xform); it must meet no Group that holds anything
+  // their run (enter_xform); it must meet no Group that holds anything a ray can hit
   size_t n_nodes = 0;
   work.assign(1, F.ord_root);
   while (!work.empty()) {
@@ -1748,13 +1753,11 @@ int64_t chip_check_culling_trees(chip_scene* s) {
         work.push_back(w.child[c]);
       }
     } else if (k == NK_GROUP) {
-      std::vector<nref_t> g(1, r);  // only Groups without content may be left
-      while (!g.empty()) {
-        const nref_t q = g.back();
-        g.pop_back();
-        if (NREF_KIND(q) != NK_GROUP) return fail("the ordered traversal would meet a Group that holds something");
-        for (uint32_t j = 0; j < F.groups[NREF_INDEX(q)].count; j++) g.push_back(F.gchild[F.groups[NREF_INDEX(q)].first + j]);
-      }
+      // the ordered traversal passes over a Group, so only Groups that reach nothing a ray can hit may be left
+      // (empty ones, or ones holding empty Groups and hierarchies without members, bvh.rs:23-26)
+      std::vector<nref_t> inside;
+      if (const char* why = ref_walk(r, inside)) return fail(why);
+      if (!inside.empty()) return fail("the ordered traversal would meet a Group that holds something");
     } else if (k == NK_TRANSLATE || k == NK_ROTATE || k == NK_SCALE) {
       const nref_t x = k == NK_TRANSLATE ? F.translates[i].enter_xform : (k == NK_ROTATE ? F.rotates[i].enter_xform : F.scales[i].enter_xform);
       const uint32_t xk = NREF_KIND(x), xi = NREF_INDEX(x);

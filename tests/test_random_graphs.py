@@ -3,12 +3,17 @@ of them, shared subgraphs, every primitive kind, a medium here and there — bui
 The culling trees of the ordered traversal are derived from these graphs at commit (hierarchies re-split, Groups
 opened, instances redirected), so this is where a mistake in that derivation would show: the CPU test checks the
 derived trees against the graph, the GPU test traces rays through both backends and compares the hits."""
+import os
+
 import numpy as np
 import pytest
 
 from helpers import compare_hits
 
 SEEDS = list(range(12))
+if os.environ.get("CHIP_TEST_GRAPH_SEEDS"):  # "FIRST:LAST" (inclusive): other seeds, for tools/fish_random_graphs.py
+    _first, _last = (int(x) for x in os.environ["CHIP_TEST_GRAPH_SEEDS"].split(":"))
+    SEEDS = list(range(_first, _last + 1))
 
 
 def random_graph(sc, seed, with_media=True):
@@ -128,7 +133,7 @@ def test_random_graphs_trace_like_the_oracle(pkg, gpu, oracle, seed):
     compare_hits(hg, ho, rel_tol=1e-12)
     # surfaces bit for bit (material kind 4 = Isotropic, CHIP_MAT_ISOTROPIC); a hit inside a medium lies at t1 + log(u) * ..., and the two libms' logarithms differ in the last place
     surf = (ho["hit"] == 1) & (ho["material_kind"] != 4)
-    assert surf.sum() > 200
+    assert surf.sum() > (200 if seed < 12 else 0)  # (a sparse graph among other seeds is no failure)
     for f in ("t", "pt", "normal"):
         assert np.array_equal(hg[f][surf].view(np.uint64), ho[f][surf].view(np.uint64)), f
     # the same rays in the reference's own visiting order (zero direction components and flagged renders take that path)
@@ -149,3 +154,47 @@ def test_random_graphs_render_like_the_oracle(pkg, gpu, oracle, seed):
     assert se["segments"] == sw["segments"]
     diff = np.abs(e.astype(np.float64) - w)
     assert (diff > 1e-3 * (1.0 + np.abs(w))).mean() < 2e-3
+
+
+def hollow_groups(sc):
+    """Groups that hold something (empty hierarchies, bvh.rs:23-26, and empty Groups) but nothing a ray can hit: as
+    the content of instances, as members of a hierarchy and of a Group, beside two spheres."""
+    m = sc.lambertian_color(0.5, 0.5, 0.5)
+    hollow = sc.group([sc.bvh([]), sc.group([]), sc.group([sc.bvh([])])])
+    world = sc.group([
+        sc.sphere((0.0, 0.0, 0.0), 1.0, m),
+        sc.rotate(hollow, (0.0, 1.0, 0.0), 30.0),
+        sc.scale(sc.group([sc.bvh([])]), 2.0, 1.0, 1.0),
+        sc.bvh([sc.sphere((3.0, 0.0, 0.0), 1.0, m), hollow, sc.translate(hollow, (1.0, 0.0, 0.0))]),
+        hollow,
+    ])
+    sc.set_world(world)
+    sc.set_lights(None)
+    sc.set_camera(image_width=32, aspect_ratio=1.0, samples_per_pixel=4, max_depth=4, vertical_fov=60, look_from=(0.0, 2.0, 18.0), look_at=(0.0, 0.0, 0.0),
+                  background=(0.6, 0.7, 0.9))
+    return sc
+
+
+def test_groups_that_reach_nothing_are_passed_over(gpu_lib):
+    assert hollow_groups(gpu_lib.new_scene()).check_culling_trees() == 2
+    only = gpu_lib.new_scene()  # a world that is nothing but such a Group
+    only.set_world(only.group([only.bvh([])]))
+    only.set_lights(None)
+    only.set_camera(image_width=8, aspect_ratio=1.0, samples_per_pixel=1, max_depth=2, vertical_fov=60, look_from=(0.0, 0.0, 5.0), look_at=(0.0, 0.0, 0.0),
+                    background=(0.5, 0.5, 0.5))
+    assert only.check_culling_trees() == 0
+
+
+@pytest.mark.gpu
+def test_hollow_groups_trace_like_the_oracle(pkg, gpu, oracle):
+    sg, so = hollow_groups(gpu.new_scene()), hollow_groups(oracle.new_scene())
+    sg.commit()
+    so.commit()
+    o, d, t = aimed_rays(5, n=20000)
+    hg, ho = sg.trace_rays(o, d, t, seed=3), so.trace_rays(o, d, t, seed=3)
+    compare_hits(hg, ho, rel_tol=1e-12)
+    assert ho["hit"].sum() > 50
+    img_a, _, sa = sg.render_frame(seed=5)
+    img_b, _, sb = sg.render_frame(seed=5, flags=pkg.bindings.RENDER_REFERENCE_ORDER)
+    assert sa["segments"] == sb["segments"]
+    assert np.array_equal(img_a.view(np.uint32), img_b.view(np.uint32))
