@@ -1087,8 +1087,11 @@ struct Rotate : Node {
   // rotate.rs:19-79
   Rotate(NodeP o, const Vec3& axis_in, double angle_deg) : object(std::move(o)) {
     double radians = angle_deg * (kPi / 180.0);  // f64::to_radians
+    // two libm calls as the source has them: a compiler that sees sin and cos of one value calls sincos instead,
+    // whose cosine is not always cos()'s to the last place (56.301153430308204 degrees: one ulp apart in glibc)
+    volatile double radians_again = radians;
     double sin_theta = std::sin(radians);
-    double cos_theta = std::cos(radians);
+    double cos_theta = std::cos(radians_again);
     Vec3 axis = axis_in.unit();
     double x = axis.x, y = axis.y, z = axis.z;
     double omc = 1.0 - cos_theta;

@@ -318,7 +318,10 @@ struct HostScene {
     n.kind = CHIP_NODE_ROTATE;
     n.c0 = child;
     double radians = deg * (kPi / 180.0);
-    double s = std::sin(radians), c = std::cos(radians);
+    // two libm calls as rotate.rs:21-22 has them: a compiler that sees sin and cos of one value may call sincos
+    // instead, whose cosine is not always cos()'s to the last place (one ulp apart at 56.301153430308204 degrees)
+    volatile double radians_again = radians;
+    double s = std::sin(radians), c = std::cos(radians_again);
     double al = std::sqrt(axis_in[0] * axis_in[0] + axis_in[1] * axis_in[1] + axis_in[2] * axis_in[2]);
     double x = axis_in[0] / al, y = axis_in[1] / al, z = axis_in[2] / al;
     double omc = 1.0 - c;

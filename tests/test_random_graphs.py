@@ -133,7 +133,7 @@ def test_random_graphs_trace_like_the_oracle(pkg, gpu, oracle, seed):
     compare_hits(hg, ho, rel_tol=1e-12)
     # surfaces bit for bit (material kind 4 = Isotropic, CHIP_MAT_ISOTROPIC); a hit inside a medium lies at t1 + log(u) * ..., and the two libms' logarithms differ in the last place
     surf = (ho["hit"] == 1) & (ho["material_kind"] != 4)
-    assert surf.sum() > (200 if seed < 12 else 0)  # (a sparse graph among other seeds is no failure)
+    assert surf.sum() > 200 or seed >= 12  # (a sparse graph among other seeds is no failure)
     for f in ("t", "pt", "normal"):
         assert np.array_equal(hg[f][surf].view(np.uint64), ho[f][surf].view(np.uint64)), f
     # the same rays in the reference's own visiting order (zero direction components and flagged renders take that path)
@@ -198,3 +198,37 @@ def test_hollow_groups_trace_like_the_oracle(pkg, gpu, oracle):
     img_b, _, sb = sg.render_frame(seed=5, flags=pkg.bindings.RENDER_REFERENCE_ORDER)
     assert sa["segments"] == sb["segments"]
     assert np.array_equal(img_a.view(np.uint32), img_b.view(np.uint32))
+
+
+def test_rotate_takes_sine_and_cosine_from_separate_calls(gpu_lib, oracle):
+    """rotate.rs:21-22 calls sin() and cos(); glibc's sincos(), which compilers substitute for such a pair, returns a
+    cosine one ulp away at this angle.  Both backends and a restatement with Python's math.sin / math.cos agree on
+    the rotated box bit for bit."""
+    import math
+    axis, deg, c0, r0 = (0.8436691021166016, 1.174500373635777, 0.7583019625898616), 56.301153430308204, (1.0, 2.0, 3.0), 0.7
+    boxes = []
+    for be in (gpu_lib, oracle):
+        sc = be.new_scene()
+        sc.set_world(sc.rotate(sc.sphere(c0, r0, sc.lambertian_color(0.5, 0.5, 0.5)), axis, deg))
+        sc.set_lights(None)
+        sc.set_camera(image_width=8, aspect_ratio=1.0, samples_per_pixel=1, max_depth=2, vertical_fov=60, look_from=(0.0, 0.0, 5.0), look_at=(0.0, 0.0, 0.0),
+                      background=(0.5, 0.5, 0.5))
+        boxes.append(sc.dump_tree()[2][0].copy())
+    rad = deg * (math.pi / 180.0)
+    s, c = math.sin(rad), math.cos(rad)
+    al = math.sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2])
+    x, y, z = (a / al for a in axis)
+    omc = 1.0 - c
+    m = [[c + x * x * omc, x * y * omc - z * s, x * z * omc + y * s], [y * x * omc + z * s, c + y * y * omc, y * z * omc - x * s],
+         [z * x * omc - y * s, z * y * omc + x * s, c + z * z * omc]]
+    lo, hi = [math.inf] * 3, [-math.inf] * 3
+    for i in (0.0, 1.0):
+        for j in (0.0, 1.0):
+            for k in (0.0, 1.0):
+                p = [f * (cc + r0) + (1.0 - f) * (cc - r0) for f, cc in zip((i, j, k), c0)]
+                for a in range(3):
+                    v = m[a][0] * p[0] + m[a][1] * p[1] + m[a][2] * p[2]
+                    lo[a], hi[a] = min(lo[a], v), max(hi[a], v)
+    want = np.array([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]])
+    assert np.array_equal(boxes[0].view(np.uint64), boxes[1].view(np.uint64))
+    assert np.array_equal(boxes[0].view(np.uint64), want.view(np.uint64))
