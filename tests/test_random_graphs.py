@@ -144,7 +144,7 @@ def test_random_graphs_trace_like_the_oracle(pkg, gpu, oracle, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", SEEDS[:4])
+@pytest.mark.parametrize("seed", SEEDS[:4] if SEEDS[0] == 0 else SEEDS)
 def test_random_graphs_render_like_the_oracle(pkg, gpu, oracle, seed):
     sg, so = random_graph(gpu.new_scene(), seed), random_graph(oracle.new_scene(), seed)
     sg.commit()
