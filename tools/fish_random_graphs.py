@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs the random-scene-graph parity tests of tests/test_random_graphs.py over seeds outside the committed set, to look
-for scene shapes the committed seeds do not reach.   usage: tools/fish_random_graphs.py FIRST LAST   (needs an MI355X)"""
+for scene shapes the committed seeds do not reach (hits, same-seed renders in both shading modes, light lists).   usage: tools/fish_random_graphs.py FIRST LAST   (needs an MI355X)"""
 import os
 import sys
 
