@@ -278,3 +278,50 @@ def test_random_graphs_with_light_lists_render_like_the_oracle(pkg, gpu, oracle,
     f, _, sf = sg.render_frame(seed=9)
     assert abs(sf["segments"] - sw["segments"]) <= 2e-3 * sw["segments"] + 2
     assert (np.abs(f.astype(np.float64) - w) > 2e-3 * (1.0 + np.abs(w))).mean() < 1e-2
+
+
+def random_sphere_world(sc, seed):
+    """1-600 bare spheres (the scenes the compact form of the traversal takes): clustered, overlapping, a few exact
+    duplicates (ties), a few hollow ones (negative radius), in one hierarchy or in hierarchies of hierarchies."""
+    rng = np.random.default_rng(9000 + seed)
+    mats = [sc.lambertian_color(0.6, 0.5, 0.4), sc.metal(0.8, 0.8, 0.9, 0.1), sc.dielectric(1.5)]
+    n = int(rng.choice([1, 2, 3, 7, 40, 200, 600]))
+    spread = float(rng.choice([0.5, 3.0, 8.0]))
+    balls = []
+    for i in range(n):
+        if balls and rng.random() < 0.05:
+            c, r = balls[int(rng.integers(len(balls)))]  # an exact duplicate
+        else:
+            c, r = tuple(float(x) for x in rng.normal(scale=spread, size=3)), float(rng.uniform(0.05, 1.5)) * (-1.0 if rng.random() < 0.05 else 1.0)
+        balls.append((c, r))
+    nodes = [sc.sphere(c, r, mats[int(rng.integers(len(mats)))]) for c, r in balls]
+    if rng.random() < 0.5 and n >= 7:
+        k = int(rng.integers(2, 6))
+        nodes = [sc.bvh(nodes[i::k]) for i in range(k)]
+    sc.set_world(sc.bvh(nodes))
+    sc.set_lights(None)
+    sc.set_camera(image_width=48, aspect_ratio=1.0, samples_per_pixel=4, max_depth=8, vertical_fov=60, look_from=(0.0, 2.0, 18.0), look_at=(0.0, 0.0, 0.0),
+                  background=(0.6, 0.7, 0.9))
+    return sc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_sphere_worlds_trace_and_render_like_the_oracle(pkg, gpu, oracle, seed):
+    sg, so = random_sphere_world(gpu.new_scene(), seed), random_sphere_world(oracle.new_scene(), seed)
+    sg.commit()
+    so.commit()
+    o, d, t = aimed_rays(300 + seed, n=20000)
+    hg, ho = sg.trace_rays(o, d, t, seed=3), so.trace_rays(o, d, t, seed=3)
+    compare_hits(hg, ho, rel_tol=1e-12)
+    hit = ho["hit"] == 1
+    for f in ("t", "pt", "normal"):
+        assert np.array_equal(hg[f][hit].view(np.uint64), ho[f][hit].view(np.uint64)), f
+    img_a, _, sa = sg.render_frame(seed=5)
+    img_b, _, sb = sg.render_frame(seed=5, flags=pkg.bindings.RENDER_REFERENCE_ORDER)
+    assert sa["segments"] == sb["segments"]
+    assert np.array_equal(img_a.view(np.uint32), img_b.view(np.uint32))
+    e, _, se = sg.render_frame(seed=9, flags=pkg.bindings.RENDER_EXACT_SHADING)
+    w, _, sw = so.render_frame(seed=9, sum_dtype=np.float64)
+    assert se["segments"] == sw["segments"]
+    assert (np.abs(e.astype(np.float64) - w) > 1e-3 * (1.0 + np.abs(w))).mean() < 2e-3
