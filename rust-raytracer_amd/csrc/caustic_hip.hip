@@ -527,7 +527,8 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   const DScene& S = D.dscene;
   const DCamera& cam = s->host.cam;
   const bool time_kernels = !noalloc && (o->flags & CHIP_RENDER_TIME_KERNELS) != 0;
-  const bool exact_shading = (o->flags & CHIP_RENDER_EXACT_SHADING) != 0;
+  // (a Disc with a normal that is not of unit length: the fast arithmetic's unit-normal shortcuts do not hold)
+  const bool exact_shading = (o->flags & CHIP_RENDER_EXACT_SHADING) != 0 || s->flat.nonunit_normals != 0;
   const uint32_t feat = scene_features(s->flat);
   // spheres with solid colours and no light sampling: the lean shade kernels
   bool solid_only = !s->flat.has_lights;

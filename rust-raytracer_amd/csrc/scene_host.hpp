@@ -104,6 +104,7 @@ struct Flat {
   nref_t root = NREF_NONE;
   uint32_t has_lights = 0, lights_is_group = 0;
   uint32_t loose_geometry = 0;  // some primitive of the world is not bounded by its own box
+  uint32_t nonunit_normals = 0;  // some Disc keeps a normal that is not of unit length (Disc::new stores it as given, disc.rs:24-41)
   uint32_t n_wide = 0;          // culling nodes in use: wnodes[0 .. n_wide)
   nref_t ord_root = NREF_NONE;  // where the ordered traversal starts: root, or the culling tree of a Group root's children
 };
@@ -474,6 +475,10 @@ struct HostScene {
       // (disc.rs:25-35); a tilted disc then sticks out of it
       {
         const double len2 = n.a[3] * n.a[3] + n.a[4] * n.a[4] + n.a[5] * n.a[5];
+        // the reference's Lambertian weighs a bounce by scattering_pdf / pdf_value, which is |normal| and not 1 on
+        // such a disc (lambertian.rs scattering_pdf takes the hit's normal as it is, the cosine pdf a unit one); the
+        // fast shading arithmetic takes the ratio as 1, so these scenes are shaded in the reference's arithmetic
+        if (!(std::fabs(len2 - 1.0) <= 1e-6)) F.nonunit_normals = 1;
         for (int i = 0; i < 3 && len2 > 0.0; i++) {
           const double reach = d.r * std::sqrt(std::fmax(0.0, 1.0 - n.a[3 + i] * n.a[3 + i] / len2));
           if (n.a[i] - reach < n.box.v[2 * i] || n.a[i] + reach > n.box.v[2 * i + 1]) F.loose_geometry = 1;

@@ -11,6 +11,7 @@ import pytest
 from helpers import compare_hits
 
 SEEDS = list(range(12))
+VARIANT = int(os.environ.get("CHIP_TEST_GRAPH_VARIANT", "0"))  # 1: discs with any normal, media bounded by turned boxes (sweeps only)
 if os.environ.get("CHIP_TEST_GRAPH_SEEDS"):  # "FIRST:LAST" (inclusive): other seeds, for tools/fish_random_graphs.py
     _first, _last = (int(x) for x in os.environ["CHIP_TEST_GRAPH_SEEDS"].split(":"))
     SEEDS = list(range(_first, _last + 1))
@@ -44,6 +45,8 @@ def random_graph(sc, seed, with_media=True, with_lights=False):
         if k == 4:  # axis-aligned normals only: a tilted disc sends the whole scene to the literal traversal
             n = [0.0, 0.0, 0.0]
             n[int(rng.integers(3))] = float(rng.choice([-1.0, 1.0]))
+            if VARIANT == 1:
+                n = [float(x) for x in rng.normal(size=3)]
             return sc.disc(point(), float(rng.uniform(0.3, 1.5)), tuple(n), mat())
         return sc.cone_frustum(point(), float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.0, 0.8)), float(rng.uniform(0.3, 1.2)), mat())
 
@@ -67,6 +70,9 @@ def random_graph(sc, seed, with_media=True, with_lights=False):
                 n = sc.translate(sc.group([sc.sphere(point(2.0), float(rng.uniform(0.2, 0.9)), mat())]), point(4.0))
             elif k == 8 and made:  # a subgraph used a second time
                 n = made[int(rng.integers(len(made)))]
+            elif k == 9 and with_media and VARIANT == 1:
+                shell = sc.translate(sc.rotate(sc.box((0, 0, 0), tuple(float(x) for x in rng.uniform(0.8, 2.5, 3)), mats[0]), (0, 1, 0), float(rng.uniform(-90, 90))), point(5.0))
+                n = sc.constant_medium_color(shell, float(rng.uniform(0.1, 1.5)), 0.9, 0.9, 0.9)
             elif k == 9 and with_media:
                 n = sc.constant_medium_color(sc.sphere(point(), float(rng.uniform(0.8, 2.0)), mats[0]), float(rng.uniform(0.1, 1.5)), 0.9, 0.9, 0.9)
             else:
@@ -325,3 +331,26 @@ def test_random_sphere_worlds_trace_and_render_like_the_oracle(pkg, gpu, oracle,
     w, _, sw = so.render_frame(seed=9, sum_dtype=np.float64)
     assert se["segments"] == sw["segments"]
     assert (np.abs(e.astype(np.float64) - w) > 1e-3 * (1.0 + np.abs(w))).mean() < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("normal", [(0.0, 0.0, 1.0), (0.3, 0.2, 1.0), (0.6, -0.5, 0.4), (0.0, 0.0, 2.0)])
+def test_disc_with_a_normal_of_any_length_renders_like_the_oracle(pkg, gpu, oracle, normal):
+    """Disc::new keeps the normal as given (disc.rs:24-41), and the reference's Lambertian then weighs every bounce
+    off the disc by |normal| (scattering_pdf / pdf_value).  The default shading mode's shortcut for unit normals does
+    not hold there, so the library shades such scenes in the reference's arithmetic: both modes equal the oracle."""
+    def build(be):
+        sc = be.new_scene()
+        m = sc.lambertian_color(0.6, 0.5, 0.4)
+        sc.set_world(sc.bvh([sc.disc((0.0, 0.0, 0.0), 5.0, normal, m), sc.sphere((0.0, 0.0, 3.0), 1.0, m)]))
+        sc.set_lights(None)
+        sc.set_camera(image_width=48, aspect_ratio=1.0, samples_per_pixel=4, max_depth=6, vertical_fov=60, look_from=(0.0, 2.0, 18.0), look_at=(0.0, 0.0, 0.0),
+                      background=(0.6, 0.7, 0.9))
+        sc.commit()
+        return sc
+    sg, so = build(gpu), build(oracle)
+    w, _, sw = so.render_frame(seed=9, sum_dtype=np.float64)
+    for flags in (pkg.bindings.RENDER_EXACT_SHADING, 0):
+        f, _, sf = sg.render_frame(seed=9, flags=flags)
+        assert sf["segments"] == sw["segments"]
+        assert (np.abs(f.astype(np.float64) - w) > 1e-3 * (1.0 + np.abs(w))).mean() < 2e-3
