@@ -85,7 +85,22 @@ def cpu_baseline(width, depth, seed):
 
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     orc = pkg.bindings.Backend(C.CDLL(oracle_so), "orc_", "oracle", sum_dtype="float64")
-    threads = min(os.cpu_count() or 1, 16)
+    # Threads: every core this process may run on (the reference starts num_cpus workers, crates/cli/src/main.rs:120),
+    # within the share of the host the job was given when the machine is shared (the launcher exports it as
+    # OMP_NUM_THREADS; os.cpu_count() names the whole machine there).
+    host_cores = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    threads = max(1, min(usable, int(share)) if share.isdigit() and int(share) > 0 else usable)
+    cpu_model = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     spp = 64
     so = pkg.scenes.build(orc, "random_spheres", width=width, spp=spp, depth=depth)
     t0 = time.perf_counter()
@@ -95,6 +110,10 @@ def cpu_baseline(width, depth, seed):
         "value": st["paths"] / dt,
         "unit": "path-samples/s",
         "cores": threads,
+        "host_cores": host_cores,
+        "cpu_model": cpu_model,
+        "threads_note": "one worker thread per core of this job's share of the host (OMP_NUM_THREADS when set, else the affinity mask); "
+                        "host_cores is what the whole machine reports",
         "kind": "port",
         "sample": f"same scene, {so.image_size()[0]}x{so.image_size()[1]}, {spp} spp (8x8 strata), depth {depth}: {st['paths']} path-samples in {dt:.1f} s",
     }
@@ -138,6 +157,9 @@ def s5_roofline(gpu, dev, seed, n, spp, prof, prof_note):
     achieved = alg / (t["ms_trace"] * 1e-3) / 1e9
     p5 = (prof or {}).get("s5") or {}
     traffic = p5.get("hbm_bytes_per_segment")
+    traffic_per_launch = traffic * t["seg"] / t["launches"] if (traffic and not prof_note) else None
+    avg_launch_s = t["ms_trace"] * 1e-3 / t["launches"]
+    frac = achieved / HBM_PEAK_GBS
     out = {
         "workload": f"OpenSCAD-shaped instance lattice {n}^3 (+ ground), {w}x{h}, {spp} spp, depth 50; built and committed in {t_build:.1f} s",
         "path_samples_per_s": t["paths"] / dt,
@@ -146,8 +168,14 @@ def s5_roofline(gpu, dev, seed, n, spp, prof, prof_note):
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic * t["seg"] / t["launches"] if (traffic and not prof_note) else None,
+        "frac": frac if frac <= 1.0 else None,
+        "traffic": traffic_per_launch,
+        # what actually crosses the L2 / memory boundary (PMC bytes per launch over the live launch duration): the figure
+        # to read against the HBM peak.  The algorithmic rate above counts every record as fetched from memory.
+        "hbm_side_GBps": traffic_per_launch / avg_launch_s / 1e9 if traffic_per_launch else None,
+        "hbm_side_frac": traffic_per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS if traffic_per_launch else None,
+        "limiter": "memory latency (dependent node fetches; waves wait most of their cycles), not bandwidth",
+        "wave_wait_share": p5.get("wave_wait_share"),
         "algorithmic_bytes_per_launch": alg / t["launches"],
         "avg_launch_ms": t["ms_trace"] / t["launches"],
         "launches": t["launches"],
@@ -155,7 +183,8 @@ def s5_roofline(gpu, dev, seed, n, spp, prof, prof_note):
         "note": "achieved prices every node / instance record as a fetch from memory; the tables (180 MB) fit the 256 MB "
                 "Infinity Cache, so `traffic` (PMC: 2 x FETCH_SIZE + WRITE_SIZE beyond L2, per launch) includes cache hits",
     }
-    assert out["frac"] <= 1.0, "S5 roofline above the HBM peak: the byte model is wrong"
+    if frac > 1.0:
+        out["note"] += f"; the modelled rate ({achieved:.0f} GB/s) exceeds the HBM peak because most records are cache hits: frac withheld"
     return out
 
 
@@ -285,8 +314,37 @@ def main():
             # nearly all of them served by LDS; a rate of its own, not a fraction of any memory's peak
             "lds_served_traversal_GBps": lds_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else None,
         }
-        if roofline["frac"] is not None:
-            assert roofline["frac"] <= 1.0, "roofline above the vector-ALU peak: the work model is wrong"
+        if roofline["frac"] is not None and roofline["frac"] > 1.0:
+            roofline["note"] = "frac above 1: the work model (lane-operations per segment from the profile) does not fit these launches"
+        # One more frame on a single stream (after the timed region): its kernels do not overlap, so the traversal and
+        # shade durations are exclusive and add up to (at most) the frame.  The timed region above runs two batches at a
+        # time on two streams, where a launch's event interval includes time it shared with the other batch's kernels.
+        exclusive = None
+        try:
+            os.environ["CHIP_STREAMS"] = "1"
+            ex_stats = []
+            ex_step = make_step(world, rank, False, flags=pkg.bindings.RENDER_TIME_KERNELS, stats_out=ex_stats)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ex_step()
+            torch.cuda.synchronize()
+            ex_ms = 1e3 * (time.perf_counter() - t1)
+            ex = traversal_sums(ex_stats)
+            ex_ach = ops_per_seg * ex["seg"] / (ex["ms_trace"] * 1e-3) / 1e12 if (usable and ex["ms_trace"] > 0) else None
+            exclusive = {
+                "what": "one frame of this rank's share with one batch in flight (CHIP_STREAMS=1), outside the timed region",
+                "frame_ms": ex_ms,
+                "traversal_ms": ex["ms_trace"],
+                "bin_and_shade_ms": ex["ms_shade"],
+                "avg_launch_ms": ex["ms_trace"] / ex["launches"] if ex["launches"] else None,
+                "achieved": ex_ach,
+                "frac": ex_ach / VALU_PEAK_TLANEOPS if ex_ach else None,
+            }
+        except Exception as e:  # an optional leg must not lose the headline line
+            exclusive = {"error": repr(e)}
+        finally:
+            os.environ.pop("CHIP_STREAMS", None)
+        roofline["exclusive"] = exclusive
         out = {
             "metric": "path-samples/sec (whole node), RTIOW final scene",
             "value": value,
@@ -307,13 +365,25 @@ def main():
                 "render_seed": args.seed,
             },
             "roofline": roofline,
+            # HIP-event intervals of the timed steps.  With two batches in flight the traversal and shade figures are sums
+            # over two streams whose kernels overlap in time, so together they exceed render_call; roofline.exclusive holds
+            # the non-overlapping figures of a one-stream frame.
             "device_ms_per_step": {
                 "render_call": tr["ms_total"] / args.steps,
-                "traversal": ms_trace / args.steps,
-                "bin_and_shade": tr["ms_shade"] / args.steps,
+                "traversal_summed_over_streams": ms_trace / args.steps,
+                "bin_and_shade_summed_over_streams": tr["ms_shade"] / args.steps,
             },
+            "shading_mode": "default (f32-seeded Newton reciprocals / f32 trigonometry in scatter directions and PDFs); checked against the oracle "
+                            "statistically (tests/test_gpu_parity.py: values within 2e-3 on >= 99 % of pixels); the bit- and segment-exact "
+                            "comparisons run CHIP_RENDER_EXACT_SHADING",
         }
-        if world == 1 and not args.no_rank_share and args.simulate_rank_of > 1:
+        def optional(name, fn):
+            try:
+                out[name] = fn()
+            except Exception as e:  # an optional leg must not lose the headline line
+                out[name] = {"error": repr(e)}
+
+        def rank_share_leg():
             # one rank's share of an N-GPU job on this GPU: every N-th stratum, no reduce
             n_sim = args.simulate_rank_of
             share = make_step(n_sim, 0, False)
@@ -324,7 +394,7 @@ def main():
                 share()
             torch.cuda.synchronize()
             ms_share = 1e3 * (time.perf_counter() - t0) / 3
-            out["rank_share"] = {
+            return {
                 "ranks": n_sim,
                 "ms_per_share": ms_share,
                 "ms_full_frame_one_gpu": ms_per_step,
@@ -332,10 +402,13 @@ def main():
                 "note": f"strata 0, {n_sim}, {2 * n_sim}, ... of every pixel on this GPU, no reduce (24.9 MB over xGMI, < 1 ms); "
                         f"the ceiling is T(1) / T(share), at most {n_sim}",
             }
+
+        if world == 1 and not args.no_rank_share and args.simulate_rank_of > 1:
+            optional("rank_share", rank_share_leg)
         if world == 1 and not args.no_s5:
-            out["roofline_s5"] = s5_roofline(gpu, dev, args.seed, args.s5_n, args.s5_spp, prof, prof_note)
+            optional("roofline_s5", lambda: s5_roofline(gpu, dev, args.seed, args.s5_n, args.s5_spp, prof, prof_note))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.width, args.depth, args.seed)
+            optional("cpu_baseline", lambda: cpu_baseline(args.width, args.depth, args.seed))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

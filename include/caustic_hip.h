@@ -231,8 +231,10 @@ int chip_render_frame_blocks(chip_scene* s, const chip_render_opts* opts, uint32
 /* 8-bit RGB PNG file of a frame (crates/cli/src/main.rs:188 `img.save`); the zlib stream uses stored blocks. */
 int chip_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb8);
 
-/* chip_render_accumulate_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  This entry point has no counterpart in the reference.  It calls no hipMalloc,
+/* chip_render_accumulate_device for callers that cannot allocate (tight serving loops, harnesses that forbid
+ * hipMalloc, code that must not disturb the allocator between graph launches).  This entry point has no counterpart in
+ * the reference.  It allocates nothing, but it is not itself capturable into a HIP graph: it reads live counts back to
+ * size later launches and synchronises `stream` before it returns.  It calls no hipMalloc,
  * hipFree, stream / event creation or other allocating routine: its path pool (32768 path slots with their counters,
  * hit records, literal queue and traversal spill slabs, about 20 MB) is a static device array that every GPU the
  * library runs on holds until the process ends, and the streams, events and pinned words it needs are made by
@@ -248,10 +250,14 @@ uint32_t chip_noalloc_max_pixels(void);
  * chip_commit_devices copies the committed scene to every device in `devices` (n entries, 1..64; an id may occur more
  * than once, each entry gets a replica of its own, which is how a one-GPU machine runs this path).  It must be called
  * again after every chip_commit.  chip_render_frame_multi then renders like chip_render_frame: replica g takes every
- * n-th of the strata the call covers (stratum_offset + g * stride, stride * n) on a host thread of its own, the f32
- * radiance sums are copied to the first device over the GPU interconnect (peer copies) and added there in replica
- * order, so the image does not depend on timing, and the first device resolves it.  The sums equal the one-GPU
- * frame's up to the order of f32 additions.  stats: counts are summed over the replicas, ms_total is the slowest. */
+ * n-th of the strata the call covers (stratum_offset + g * stride, stride * n) on a host thread and stream of its own;
+ * as soon as a replica has finished, its f32 radiance sums travel to a staging slot of its own on the first device
+ * (peer copy over the GPU interconnect, while slower replicas still render), and one kernel adds the slots in replica
+ * order, so the image does not depend on timing; the first device resolves it.  The sums equal the one-GPU frame's up
+ * to the order of f32 additions.  A call that covers fewer strata than there are replicas is dealt as bands of rows of
+ * the rectangle instead (the reference deals blocks of pixels, main.rs:83-106): replica g renders every stratum of
+ * band g and the bands are copied side by side, which gives the one-GPU frame bit for bit.
+ * stats: counts are summed over the replicas, ms_total is the slowest. */
 int chip_commit_devices(chip_scene* s, const int* devices, int n);
 int chip_render_frame_multi(chip_scene* s, const chip_render_opts* opts, float* out_sum_rgb, uint8_t* out_rgb8, chip_stats* stats);
 

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -89,6 +90,11 @@ struct EventBag {
 // for the device at hand (DeviceState::noalloc_base).
 #define CHIP_NOALLOC_PATHS 32768u
 #define CHIP_NOALLOC_COUNTER_ROWS 256u
+#define CHIP_NOALLOC_MAX_BLOCK 1024u  // largest traversal block (extend_block)
+#define CHIP_NOALLOC_OVF_SLABS (CHIP_NOALLOC_PATHS + CHIP_NOALLOC_MAX_BLOCK)
+static_assert(extend_block(0, true) <= (int)CHIP_NOALLOC_MAX_BLOCK && extend_block(TF_QUADS | TF_XFORM, true) <= (int)CHIP_NOALLOC_MAX_BLOCK &&
+                  extend_block(TF_MEDIA, true) <= (int)CHIP_NOALLOC_MAX_BLOCK && CHIP_BLOCK <= (int)CHIP_NOALLOC_MAX_BLOCK,
+              "the static spill slab must cover a grid rounded up to the largest traversal block");
 struct NoAllocLayout {
   PathRay ray[2 * CHIP_NOALLOC_PATHS];
   PathMap st[2 * CHIP_NOALLOC_PATHS];
@@ -96,7 +102,9 @@ struct NoAllocLayout {
   float4 sample[CHIP_NOALLOC_PATHS];
   uint32_t qlit[CHIP_NOALLOC_PATHS];
   uint32_t counters[CHIP_NOALLOC_COUNTER_ROWS * CHIP_CTR_STRIDE];
-  uint32_t ovf[(size_t)CHIP_NOALLOC_PATHS * 2 * CHIP_STACK_OVF];  // one spill slab per thread; a launch has at most one thread per slot
+  // one spill slab per thread of a traversal launch: the grid covers the live paths rounded up to whole blocks, so a
+  // launch over a full pool has up to one block less one thread more than slots (launch_extend_b checks the bound)
+  uint32_t ovf[(size_t)CHIP_NOALLOC_OVF_SLABS * 2 * CHIP_STACK_OVF];
   uint32_t err[4];
   unsigned long long stats[4];
 };
@@ -161,6 +169,7 @@ struct DeviceState {
   DevBuf<unsigned long long> p_stats;
   uint32_t* h_pinned = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr;
+  hipStream_t multi_stream = nullptr;  // chip_render_frame_multi: the stream this replica's render forks from and its sums leave on
   DevBuf<float> frame_sum, frame_stage;  // chip_render_frame's radiance sums; a peer's sums on their way into them
   DevBuf<uint8_t> frame_rgb8;
   unsigned char* noalloc_base = nullptr;  // this device's copy of `scratch`
@@ -194,6 +203,8 @@ struct DeviceState {
       *e = nullptr;
     }
     frame_sum.release(); frame_stage.release(); frame_rgb8.release();
+    if (multi_stream) (void)hipStreamDestroy(multi_stream);
+    multi_stream = nullptr;
     res_ready = false;
     noalloc_base = nullptr;
     noalloc_pool = PathPool{};
@@ -268,6 +279,7 @@ static int ensure_resources(DeviceState& D) {
   if (!D.ev0) HIP_TRY(hipEventCreate(&D.ev0));
   if (!D.ev1) HIP_TRY(hipEventCreate(&D.ev1));
   if (!D.ev_fork) HIP_TRY(hipEventCreateWithFlags(&D.ev_fork, hipEventDisableTiming));
+  if (!D.multi_stream) HIP_TRY(hipStreamCreateWithFlags(&D.multi_stream, hipStreamNonBlocking));
   {
     void* base = nullptr;
     HIP_TRY(hipGetSymbolAddress(&base, HIP_SYMBOL(scratch)));
@@ -280,13 +292,17 @@ static int ensure_resources(DeviceState& D) {
     P.hit = L->hit; P.sample = L->sample; P.q_lit = L->qlit;
     P.counters = L->counters; P.errflag = L->err; P.stats = L->stats; P.ovf = L->ovf;
     P.cap = CHIP_NOALLOC_PATHS;
+    P.ovf_slabs = CHIP_NOALLOC_OVF_SLABS;
   }
   D.res_ready = true;
   return 0;
 }
 
 // Makes pool `which` hold min(want_paths, max_paths, what fits in free device memory) path slots.
-static int ensure_pool(const chip_scene* s, DeviceState& D, int which, size_t want_paths, size_t max_paths) {
+// Replicas of one device allocate one after the other (a process-wide lock), each keeping to its share of the free memory.
+static std::mutex g_pool_mutex;
+static int ensure_pool(const chip_scene* s, DeviceState& D, int which, size_t want_paths, size_t max_paths, int mem_share = 1) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
   PoolBufs& pb = D.pools[which];
   uint32_t rows = s->host.cam.max_depth + 2;
   size_t cap = std::min(std::max<size_t>(want_paths, 4096), std::max<size_t>(max_paths, 4096));
@@ -294,7 +310,7 @@ static int ensure_pool(const chip_scene* s, DeviceState& D, int which, size_t wa
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     if (pb.ready) free_b += (size_t)pb.P.cap * kBytesPerPathSlot;
-    cap = std::min(cap, std::max<size_t>(4096, (size_t)(0.8 * (double)free_b) / kBytesPerPathSlot));
+    cap = std::min(cap, std::max<size_t>(4096, (size_t)(0.8 * (double)free_b / (double)std::max(mem_share, 1)) / kBytesPerPathSlot));
   }
   if (ensure_resources(D)) return -1;
   if (pb.ready && pb.P.cap >= cap && pb.counters_rows >= rows) return 0;
@@ -318,6 +334,7 @@ static int ensure_pool(const chip_scene* s, DeviceState& D, int which, size_t wa
   P.ray[0] = pb.ray.p; P.ray[1] = pb.ray.p + P.cap; P.st[0] = pb.st.p; P.st[1] = pb.st.p + P.cap;
   P.hit = pb.hit.p; P.sample = pb.sample.p; P.q_lit = pb.qlit.p;
   P.counters = pb.counters.p; P.errflag = D.p_err.p; P.stats = D.p_stats.p; P.ovf = pb.ovf.p;
+  P.ovf_slabs = kMaxGridBlocks * CHIP_BLOCK;
   pb.ready = true;
   return 0;
 }
@@ -369,18 +386,33 @@ struct ExtendPlan {
   uint32_t block, lds_bytes;
 };
 static const uint32_t kLdsBytes = 160 * 1024;
+// Tuning knobs read from the environment, once per render call (tests change them between calls of one process).
+struct EnvKnobs {
+  bool no_lds_cache = false, no_small = false;
+  int lds_stack = 0;          // 0 = the variant's default
+  uint32_t small_stack = 16;  // stack words per lane of the compact form
+  uint32_t small_queue = 16384;
+  static EnvKnobs read() {
+    EnvKnobs k;
+    if (const char* e = getenv("CHIP_NO_LDS_CACHE")) k.no_lds_cache = *e == '1';
+    if (const char* e = getenv("CHIP_NO_SMALL_FORM")) k.no_small = *e == '1';
+    if (const char* e = getenv("CHIP_LDS_STACK")) { int v = atoi(e); if (v >= 2 && v <= 16) k.lds_stack = v; }
+    if (const char* e = getenv("CHIP_SMALL_STACK")) { int v = atoi(e); if (v >= 4 && v <= 24) k.small_stack = (uint32_t)v; }
+    if (const char* e = getenv("CHIP_SMALL_QUEUE")) { if (*e) k.small_queue = (uint32_t)atol(e); }
+    return k;
+  }
+};
 // uncached: the plain 256-thread form (literal passes)
-static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached) {
+static ExtendPlan plan_extend(const chip_scene* s, const EnvKnobs& env, uint32_t feat, bool uncached) {
   ExtendPlan p;
-  const char* e = getenv("CHIP_NO_LDS_CACHE");
-  p.cache = !uncached && !s->flat.bvh.empty() && !(e && *e == '1');
+  p.cache = !uncached && !s->flat.bvh.empty() && !env.no_lds_cache;
   if (p.cache) {
     p.block = (uint32_t)extend_block(feat, true);
     // (value, entry distance) pairs per lane kept in LDS; the rest of a deep descent goes to the spill slab.  Deep
     // trees read from memory (instanced spheres) gain more from two further entries than from the 140 nodes of
     // cache they cost; the sphere scenes' trees are shallow
     p.cd.stack_entries = (feat & TF_NO_QUADROT) ? 10 : 8;
-    if (const char* es = getenv("CHIP_LDS_STACK")) { int v = atoi(es); if (v >= 2 && v <= 16) p.cd.stack_entries = (uint32_t)v; }
+    if (env.lds_stack) p.cd.stack_entries = (uint32_t)env.lds_stack;
     const uint32_t stack_bytes = (p.cd.stack_entries + 1) * 8 * p.block;  // (+ the spare entry of st_push_sel)
     const uint32_t node_bytes = 16 * CHIP_WNODE_U4, sphere_bytes = 64;
     uint32_t budget = kLdsBytes - stack_bytes;
@@ -389,12 +421,9 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
     p.cd.n_sph = (uint32_t)std::min<size_t>(s->flat.spheres.size(), budget / sphere_bytes);
     p.lds_bytes = node_bytes * p.cd.n_bvh + sphere_bytes * p.cd.n_sph + stack_bytes;
     // the compact form: planned on its own (4-byte stack words, the whole scene cached or not at all)
-    const char* e_no_small = getenv("CHIP_NO_SMALL_FORM");
-    const bool no_small = e_no_small && *e_no_small == '1';
-    uint32_t small_entries = 16;
-    if (const char* es = getenv("CHIP_SMALL_STACK")) { int v = atoi(es); if (v >= 4 && v <= 24) small_entries = (uint32_t)v; }
+    const uint32_t small_entries = env.small_stack;
     const size_t small_bytes = node_bytes * s->flat.n_wide + sphere_bytes * s->flat.spheres.size() + (size_t)small_entries * 4 * p.block;
-    p.small = !no_small && feat == 0 && s->flat.n_wide <= CHIP_SM_MAX && s->flat.spheres.size() <= CHIP_SM_MAX && small_bytes <= kLdsBytes;
+    p.small = !env.no_small && feat == 0 && s->flat.n_wide <= CHIP_SM_MAX && s->flat.spheres.size() <= CHIP_SM_MAX && small_bytes <= kLdsBytes;
     if (p.small) {
       p.cd.stack_entries = small_entries;
       p.cd.n_bvh = (uint32_t)s->flat.n_wide;
@@ -410,6 +439,14 @@ static ExtendPlan plan_extend(const chip_scene* s, uint32_t feat, bool uncached)
   }
   return p;
 }
+// The launch shapes of one render call: planned once, used by every bounce.
+struct ExtendPlans {
+  uint32_t feat;         // the feature set whose instantiation runs (extend_variant)
+  ExtendPlan lit;        // the literal passes: the plain 256-thread form
+  ExtendPlan full;       // long queues: the LDS-cached form when the scene has one
+  ExtendPlan shortq;     // short queues (the late bounces)
+  uint32_t small_queue;  // queues below this many entries are short
+};
 template <uint32_t F, bool CACHE, bool ORD, bool B0>
 static int launch_extend_b(const DeviceState& D, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
                            uint32_t bounce, uint32_t lit_pass) {
@@ -433,6 +470,8 @@ static int launch_extend_b(const DeviceState& D, const PathPool& P, const Extend
     threads = 64u;
     lds_bytes = (p.cd.stack_entries + 1u) * 8u * threads;
   }
+  // every thread of the launch owns a spill slab: the grid must not be larger than the pool's slab array
+  if ((size_t)blocks * threads > P.ovf_slabs) return fail("internal: traversal launch larger than the pool's spill slabs");
   hipLaunchKernelGGL((k_extend<F, CACHE, ORD, B0>), dim3(blocks), dim3(threads), lds_bytes, st, D.dscene, P, B, bounce, p.cd, lit_pass);
   return 0;
 }
@@ -471,20 +510,29 @@ static uint32_t extend_variant(uint32_t feat) {
     default: return TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT | TF_MEDIA_ANY;
   }
 }
+static ExtendPlans plan_extends(const chip_scene* s, uint32_t scene_feat) {
+  const EnvKnobs env = EnvKnobs::read();
+  ExtendPlans X;
+  // the launch shape (threads per block, LDS split) must be planned for the instantiation that runs
+  X.feat = extend_variant(scene_feat);
+  X.lit = plan_extend(s, env, X.feat, true);
+  X.full = plan_extend(s, env, X.feat, false);
+  // A short queue (the late bounces) is not worth a CU-filling block and its copy of the scene tables: it runs the
+  // plain 256-thread form, whose blocks also find room sooner beside the other batch's kernels (+2 % on the sphere
+  // and Cornell scenes).  Not for instanced spheres: their deep trees want the cached top levels even then.
+  X.shortq = (X.feat & TF_NO_QUADROT) ? X.full : X.lit;
+  X.small_queue = env.small_queue;
+  return X;
+}
 // One bounce of traversal: the ordered traversal followed by a literal pass over the rays it handed back (normally none; all of
 // them in a reference_order render).
 // lit_expected: whether the literal queue is expected to hold rays (it sizes the literal pass's grid only: one block
 // drains a queue of any length, slowly).
-static int launch_extend(const chip_scene* s, const DeviceState& D, const PathPool& P, uint32_t feat, uint32_t n_live_upper, hipStream_t st,
+static int launch_extend(const DeviceState& D, const PathPool& P, const ExtendPlans& X, uint32_t n_live_upper, hipStream_t st,
                          const BatchDesc& B, uint32_t bounce, bool lit_expected) {
-  // the launch shape (threads per block, LDS split) must be planned for the instantiation that runs
-  feat = extend_variant(feat);
-  const ExtendPlan lit = plan_extend(s, feat, true);
-  // A short queue (the late bounces) is not worth a CU-filling block and its copy of the scene tables: it runs the
-  // plain 256-thread form, whose blocks also find room sooner beside the other batch's kernels (+2 % on the sphere
-  // and Cornell scenes).  Not for instanced spheres: their deep trees want the cached top levels even then.
-  static const uint32_t small_queue = [] { const char* e = getenv("CHIP_SMALL_QUEUE"); return e && *e ? (uint32_t)atol(e) : 16384u; }();
-  const ExtendPlan p = plan_extend(s, feat, !(feat & TF_NO_QUADROT) && n_live_upper < small_queue);
+  const uint32_t feat = X.feat;
+  const ExtendPlan& lit = X.lit;
+  const ExtendPlan& p = n_live_upper < X.small_queue ? X.shortq : X.full;
   const uint32_t lit_upper = B.reference_order ? n_live_upper : (lit_expected ? std::min<uint32_t>(n_live_upper, 64u * CHIP_BLOCK) : 1u);
 #define CHIP_EXT(FEAT)                                                                                   \
   {                                                                                                      \
@@ -519,8 +567,9 @@ static int launch_extend(const chip_scene* s, const DeviceState& D, const PathPo
 // independent of how the device interleaved them.
 // With `noalloc` the call uses the device's static scratch pool on the caller's stream (one batch at a time) and
 // the streams, events and pinned words made at commit: it allocates nothing.
+// mem_share: how many concurrent render calls share this device's free memory (replicas of one device).
 static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o, const RenderPlan& pl, float* d_sum, hipStream_t stream,
-                       chip_stats* stats, bool noalloc) {
+                       chip_stats* stats, bool noalloc, int mem_share = 1) {
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(D.device));
   if (!D.uploaded) return fail("scene not committed on this device");
@@ -530,6 +579,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   // (a Disc with a normal that is not of unit length: the fast arithmetic's unit-normal shortcuts do not hold)
   const bool exact_shading = (o->flags & CHIP_RENDER_EXACT_SHADING) != 0 || s->flat.nonunit_normals != 0;
   const uint32_t feat = scene_features(s->flat);
+  const ExtendPlans xplans = plan_extends(s, feat);
   // spheres with solid colours and no light sampling: the lean shade kernels
   bool solid_only = !s->flat.has_lights;
   for (const DTexture& t : s->host.textures) solid_only = solid_only && t.kind == TK_SOLID;
@@ -560,7 +610,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
     const size_t max_each = pool_capacity_max() / (size_t)n_lanes;
     const size_t want_each = (size_t)pl.rw * pl.rh * ((std::max<uint32_t>(pl.s_count, 1) + n_lanes - 1) / n_lanes);
     for (int k = 0; k < n_lanes; k++)
-      if (ensure_pool(s, D, k, want_each, max_each)) return -1;
+      if (ensure_pool(s, D, k, want_each, max_each, mem_share)) return -1;
     cap = D.pools[0].P.cap;
     for (int k = 1; k < n_lanes; k++) cap = std::min<size_t>(cap, D.pools[k].P.cap);
     if (pl.rw > cap) return fail("render rectangle is wider than the path pool");
@@ -683,7 +733,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
       const uint32_t bounce = L.bounce;
       const uint32_t grid = std::min(grid_for(L.live_upper), shade_grid_max);
       if (time_kernels && stamp()) return -1;
-      if (launch_extend(s, D, P, feat, L.live_upper, L.st, B, bounce, L.lit_expected)) {
+      if (launch_extend(D, P, xplans, L.live_upper, L.st, B, bounce, L.lit_expected)) {
         bag.failed = true;
         return -1;
       }
@@ -877,9 +927,19 @@ static int upload_scene(chip_scene* s, DeviceState& D, const Flat& F) {
   return 0;
 }
 
-// a += b over n floats (the sums of another GPU added to this one's)
-__global__ void __launch_bounds__(CHIP_BLOCK) k_add_sums(float* a, const float* b, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i];
+// a += src[0] + src[1] + ... over n floats, each element's additions in list order (the sums of other GPUs added to
+// this one's: the same bits whichever GPU finished first)
+#define CHIP_ADD_MAX 16
+struct AddList {
+  const float* src[CHIP_ADD_MAX];
+  uint32_t n;
+};
+__global__ void __launch_bounds__(CHIP_BLOCK) k_add_sums(float* a, AddList L, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = a[i];
+    for (uint32_t k = 0; k < L.n; k++) v += L.src[k][i];
+    a[i] = v;
+  }
 }
 
 extern "C" {
@@ -1418,51 +1478,105 @@ int chip_render_frame_multi(chip_scene* s, const chip_render_opts* opts, float* 
   const size_t npix = (size_t)pl.rw * pl.rh;
   const uint32_t stride0 = opts->stratum_stride ? opts->stratum_stride : 1;
   DeviceGuard guard;
-  // replica g takes every n-th of the strata this call covers (crates/cli/src/main.rs:119-163 deals blocks of
-  // pixels to threads; the samples of a pixel are just as independent, camera.rs:335-341)
-  std::vector<int> rc((size_t)n, 0);
-  std::vector<std::string> err((size_t)n);
-  std::vector<chip_stats> st((size_t)n);
+  // How the call is dealt to the replicas.  With at least as many strata as replicas, replica g takes every n-th of
+  // the strata this call covers (crates/cli/src/main.rs:119-163 deals blocks of pixels to threads; the samples of a
+  // pixel are just as independent, camera.rs:335-341) and the replicas' sums are added.  With fewer strata than
+  // replicas (a progressive pass, a low-spp preview) that would leave GPUs idle, so the rectangle is cut into bands of
+  // rows instead, as the reference cuts the image into blocks (main.rs:83-106): replica g renders every stratum of
+  // band g, and the bands are copied side by side, with no addition at all.
+  const bool by_rows = pl.s_count < (uint32_t)n && pl.rh >= 2;
+  const int n_used = by_rows ? (int)std::min<uint32_t>((uint32_t)n, pl.rh) : n;
+  auto band_row = [&](int g) -> uint32_t {  // first row of band g, on multiples of 8 rows where the rectangle allows
+    if (g >= n_used) return pl.rh;
+    const uint32_t unit = pl.rh >= 8u * (uint32_t)n_used ? 8u : 1u;
+    return (uint32_t)((uint64_t)(pl.rh / unit) * (uint32_t)g / (uint32_t)n_used) * unit;
+  };
+  DeviceState& D0 = *s->replicas[0];
+  // replicas per device: the path pools of replicas that share a device share its free memory
+  std::vector<int> share((size_t)n, 1);
   for (int g = 0; g < n; g++) {
+    int c = 0;
+    for (int h = 0; h < n_used; h++) c += s->replicas[(size_t)h]->device == s->replicas[(size_t)g]->device ? 1 : 0;
+    share[(size_t)g] = std::max(c, 1);
+  }
+  for (int g = 0; g < n_used; g++) {
     DeviceState& D = *s->replicas[(size_t)g];
     HIP_TRY(hipSetDevice(D.device));
+    if (ensure_resources(D)) return -1;
     HIP_TRY(D.frame_sum.reserve(npix * 3));
-    HIP_TRY(hipMemsetAsync(D.frame_sum.p, 0, npix * 3 * sizeof(float), nullptr));
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemsetAsync(D.frame_sum.p, 0, npix * 3 * sizeof(float), D.multi_stream));
+    HIP_TRY(hipStreamSynchronize(D.multi_stream));  // (other replicas write into the first one's buffer in the row-band mode)
   }
-  std::vector<std::thread> workers;
-  for (int g = 0; g < n; g++)
-    workers.emplace_back([&, g]() {
-      chip_render_opts o = *opts;
-      o.stratum_offset = opts->stratum_offset + (uint32_t)g * stride0;
-      o.stratum_stride = stride0 * (uint32_t)n;
-      RenderPlan plg;
+  HIP_TRY(hipSetDevice(D0.device));
+  // a staging slot on the first device for every replica that lives on another one (strata mode)
+  std::vector<const float*> src((size_t)n_used, nullptr);
+  if (!by_rows) {
+    size_t slots = 0;
+    for (int g = 1; g < n_used; g++) slots += s->replicas[(size_t)g]->device != D0.device ? 1 : 0;
+    if (slots) HIP_TRY(D0.frame_stage.reserve(slots * npix * 3));
+    size_t k = 0;
+    for (int g = 0; g < n_used; g++) {
       DeviceState& D = *s->replicas[(size_t)g];
-      rc[(size_t)g] = plan_render(s, &o, plg);
-      if (rc[(size_t)g] == 0) rc[(size_t)g] = render_into(s, D, &o, plg, D.frame_sum.p, D.lanes[kMaxLanes - 1].stream, &st[(size_t)g], false);
-      if (rc[(size_t)g]) err[(size_t)g] = g_err;  // (the message lives in this thread)
+      src[(size_t)g] = (g == 0 || D.device == D0.device) ? D.frame_sum.p : D0.frame_stage.p + (k++) * npix * 3;
+    }
+  }
+  std::vector<int> rc((size_t)n_used, 0);
+  std::vector<std::string> err((size_t)n_used);
+  std::vector<chip_stats> st((size_t)n_used);
+  // One host thread per replica: it renders on the replica's own stream and, as soon as its sums are complete, sends
+  // them to the first device from that same stream, so the transfers of replicas that finish early run while the
+  // others still render.
+  std::vector<std::thread> workers;
+  for (int g = 0; g < n_used; g++)
+    workers.emplace_back([&, g]() {
+      DeviceState& D = *s->replicas[(size_t)g];
+      auto bad = [&](const std::string& what) {
+        rc[(size_t)g] = -1;
+        err[(size_t)g] = what;
+      };
+      chip_render_opts o = *opts;
+      RenderPlan plg = pl;
+      if (by_rows) {
+        const uint32_t r0 = band_row(g), r1 = band_row(g + 1);
+        if (r1 <= r0) return;
+        plg.ymin = pl.ymin + r0; plg.ymax = pl.ymin + r1; plg.rh = r1 - r0;
+      } else {
+        o.stratum_offset = opts->stratum_offset + (uint32_t)g * stride0;
+        o.stratum_stride = stride0 * (uint32_t)n_used;
+        if (plan_render(s, &o, plg)) return bad(g_err);
+      }
+      if (render_into(s, D, &o, plg, D.frame_sum.p, D.multi_stream, &st[(size_t)g], false, share[(size_t)g])) return bad(g_err);  // (the message lives in this thread)
+      hipError_t e = hipSetDevice(D.device);
+      if (e == hipSuccess && by_rows && g > 0) {
+        // band g of the first device's frame, straight from this replica's band buffer
+        float* dst = D0.frame_sum.p + (size_t)band_row(g) * pl.rw * 3;
+        const size_t bytes = (size_t)plg.rh * pl.rw * 3 * sizeof(float);
+        e = D.device == D0.device ? hipMemcpyAsync(dst, D.frame_sum.p, bytes, hipMemcpyDeviceToDevice, D.multi_stream)
+                                  : hipMemcpyPeerAsync(dst, D0.device, D.frame_sum.p, D.device, bytes, D.multi_stream);
+      } else if (e == hipSuccess && !by_rows && src[(size_t)g] != D.frame_sum.p) {
+        e = hipMemcpyPeerAsync(const_cast<float*>(src[(size_t)g]), D0.device, D.frame_sum.p, D.device, npix * 3 * sizeof(float), D.multi_stream);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(D.multi_stream);
+      if (e != hipSuccess) bad(std::string("gathering the sums: ") + hipGetErrorString(e));
     });
   for (std::thread& t : workers) t.join();
-  for (int g = 0; g < n; g++)
+  for (int g = 0; g < n_used; g++)
     if (rc[(size_t)g]) return fail("replica " + std::to_string(g) + ": " + err[(size_t)g]);
-  // sums of replicas 1 .. n-1 onto replica 0's device, added in replica order (so the result does not depend on timing)
-  DeviceState& D0 = *s->replicas[0];
   HIP_TRY(hipSetDevice(D0.device));
-  if (n > 1) HIP_TRY(D0.frame_stage.reserve(npix * 3));
-  for (int g = 1; g < n; g++) {
-    DeviceState& D = *s->replicas[(size_t)g];
-    const float* src = D.frame_sum.p;
-    if (D.device != D0.device) {
-      HIP_TRY(hipMemcpyPeerAsync(D0.frame_stage.p, D0.device, D.frame_sum.p, D.device, npix * 3 * sizeof(float), nullptr));
-      src = D0.frame_stage.p;
+  if (!by_rows && n_used > 1) {
+    // one pass adds the replicas' sums in replica order, so the result does not depend on which finished first
+    AddList L;
+    for (int g0 = 1; g0 < n_used; g0 += CHIP_ADD_MAX) {
+      L.n = (uint32_t)std::min(CHIP_ADD_MAX, n_used - g0);
+      for (uint32_t k = 0; k < L.n; k++) L.src[k] = src[(size_t)g0 + k];
+      hipLaunchKernelGGL(k_add_sums, dim3(grid_for(npix * 3)), dim3(CHIP_BLOCK), 0, D0.multi_stream, D0.frame_sum.p, L, npix * 3);
+      HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_add_sums, dim3(grid_for(npix * 3)), dim3(CHIP_BLOCK), 0, nullptr, D0.frame_sum.p, src, npix * 3);
-    HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(D0.multi_stream));
   if (stats) {
     *stats = st[0];
-    for (int g = 1; g < n; g++) {
+    for (int g = 1; g < n_used; g++) {
       stats->paths += st[(size_t)g].paths; stats->segments += st[(size_t)g].segments; stats->bvh_visits += st[(size_t)g].bvh_visits;
       stats->prim_tests += st[(size_t)g].prim_tests; stats->trace_launches += st[(size_t)g].trace_launches; stats->batches += st[(size_t)g].batches;
       stats->ms_total = std::max(stats->ms_total, st[(size_t)g].ms_total);

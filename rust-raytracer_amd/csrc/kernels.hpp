@@ -96,8 +96,9 @@ struct PathPool {
   uint32_t* counters;   // [max_depth+2][CHIP_CTR_STRIDE]: [b][0] entries of bounce b, then the cursors of the traversal kernels
   uint32_t* errflag;    // [4]: [0] traversal stack overflow
   unsigned long long* stats;  // [4]: segments, bvh visits, prim tests, spare
-  uint32_t* ovf;        // [threads][2 * CHIP_STACK_OVF] traversal stack spill (value, distance pairs)
+  uint32_t* ovf;        // [ovf_slabs][2 * CHIP_STACK_OVF] traversal stack spill (value, distance pairs), one slab per thread of a launch
   uint32_t cap;
+  uint32_t ovf_slabs;
 };
 
 struct BatchDesc {

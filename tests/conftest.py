@@ -14,6 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
+    # (pytest-timeout registers this mark itself when it is installed; registered here so that the mark is known without it)
+    config.addinivalue_line("markers", "timeout(seconds): per-test time limit, enforced by pytest-timeout when installed")
 
 
 @pytest.fixture(scope="session")

@@ -52,3 +52,36 @@ def test_multi_needs_commit_devices_and_follows_recommit(pkg, gpu):
     b, _, _ = sc.render_frame(seed=1, multi=True)
     c, _, _ = sc.render_frame(seed=1)
     assert np.allclose(b, c, rtol=1e-5, atol=1e-5) and a.max() > 0
+
+
+def test_eight_replicas_full_size_frame_and_row_bands(pkg, gpu):
+    """Eight replicas (the 8-GPU node's shape; on a one-GPU machine the device list names that GPU eight times) at the
+    benchmark's frame size.  With 64 strata every replica takes eight of them and the sums are added in replica order:
+    the bits of the same eight renders added on the host.  With 4 strata there are fewer strata than replicas, so the
+    call is dealt as bands of rows instead (crates/cli/src/main.rs:83-106 deals blocks of pixels): every pixel's samples
+    are then added on one replica, in stratum order, and the frame is the single-device frame bit for bit."""
+    n_dev = pkg.gpu_device_count()
+    devices = [g % n_dev for g in range(8)]
+    sc = pkg.scenes.build(gpu, "random_spheres", width=1920, spp=64, depth=50)
+    assert sc.image_size() == (1920, 1080)
+    sc.commit_devices(devices)
+    multi, _, sm = sc.render_frame(seed=11, multi=True)
+    assert sm["paths"] == 1920 * 1080 * 64
+    want = None
+    segs = 0
+    for g in range(8):
+        part, _, st = sc.render_frame(seed=11, stratum_offset=g, stratum_stride=8)
+        segs += st["segments"]
+        want = part.copy() if want is None else want + part
+    assert sm["segments"] == segs
+    assert np.array_equal(multi.view(np.uint32), want.view(np.uint32))
+    # fewer strata than replicas: a call that covers strata 3, 19, 35, 51 of the 64
+    few, _, sf = sc.render_frame(seed=11, stratum_offset=3, stratum_stride=16, multi=True)
+    one, _, so = sc.render_frame(seed=11, stratum_offset=3, stratum_stride=16)
+    assert sf["paths"] == so["paths"] == 1920 * 1080 * 4 and sf["segments"] == so["segments"]
+    assert sf["batches"] >= 8  # one band per replica
+    assert np.array_equal(few.view(np.uint32), one.view(np.uint32))
+    # ... also on a rectangle whose height is not a multiple of anything convenient
+    rect = (100, 740, 37, 300)
+    a, _, _ = sc.render_frame(seed=11, rect=rect, stratum_offset=3, stratum_stride=16, multi=True)
+    assert np.array_equal(a.view(np.uint32), one[rect[2]:rect[3], rect[0]:rect[1]].view(np.uint32))

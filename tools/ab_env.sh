@@ -9,6 +9,6 @@ for rep in $(seq 1 "$REPS"); do
     env $setting timeout -k 10 180 python bench.py $ARGS --no-cpu-baseline --no-s5 --no-rank-share 2>&1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); m=d['device_ms_per_step']
-print('%.1f Mpaths/s  wall %.1f ms/step | trav %.1f  bin+shade %.1f' % (d['value']/1e6, d['ms_per_step'], m['traversal'], m['bin_and_shade']))" || exit 1
+print('%.1f Mpaths/s  wall %.1f ms/step | trav %.1f  bin+shade %.1f' % (d['value']/1e6, d['ms_per_step'], m['traversal_summed_over_streams'], m['bin_and_shade_summed_over_streams']))" || exit 1
   done
 done
