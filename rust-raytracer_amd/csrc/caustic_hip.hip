@@ -865,6 +865,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   }
 #undef RENDER_TRY
   if (D.h_pinned[8] & 1u) return fail("traversal stack overflow (scene nesting deeper than the device stack)");
+  if (D.h_pinned[9] & 1u) return fail("internal: a path record named a path outside the batch");
   if (stats) {
     const unsigned long long* st = (const unsigned long long*)(D.h_pinned + 16);
     stats->paths = n_paths_total;

@@ -83,9 +83,15 @@ struct alignas(16) PathHit {  // what traversal writes: closest hit of the curre
                   // defocus-disk candidates the camera ray consumed
 };
 #define PATHHIT_TRIES(info) ((info) >> 24)
-struct alignas(16) PathMap {  // x -> clamp(b x, lo, hi), the composed radiance map of the path so far, and the path id
-  uint32_t id, pad[2];
-  float b[3], lo[3], hi[3];
+// The composed radiance map of the path so far, x -> b x before the first bounce that clamps (camera.rs:304) and
+// x -> clamp(b x, min(0, bound), max(0, bound)) after it, and the path id.  One end of the clamp interval is always
+// zero (the clamp of camera.rs:304 is [0, 10] and every later bounce only scales and clips it), so the record holds the
+// other end and one bit instead of two ends per channel.
+#define CHIP_MAP_CLAMPED 0x80000000u  // in PathMap::id: a clamping bounce has happened (path ids stay below 2^31)
+struct alignas(32) PathMap {
+  uint32_t id;
+  float b[3], bound[3];
+  uint32_t pad;
 };
 struct PathPool {
   PathRay* ray[2];  // [cap] each: entries of even / odd bounces
@@ -1369,24 +1375,31 @@ __device__ inline float fclampf(float v, float lo, float hi) { return v < lo ? l
 // The radiance map of a path that is still alive has no constant term: a material that scatters emits nothing
 // (material/mod.rs default `emitted`), and the one that emits (diffuse_light.rs:28-43) ends the path.
 struct Affine {
-  float b[3], lo[3], hi[3];
+  float b[3], bound[3];
+  uint32_t clamped;  // 0 or CHIP_MAP_CLAMPED
 };
-// One bounce of camera.rs:274-304 as the per-channel map x -> clamp(w x, klo, khi),
-// composed on the right of the path's x -> clamp(b x, lo, hi).
+__device__ inline float affine_lo(const Affine& f, int c) { return f.clamped ? fminf(0.f, f.bound[c]) : -CHIP_BIG; }
+__device__ inline float affine_hi(const Affine& f, int c) { return f.clamped ? fmaxf(0.f, f.bound[c]) : CHIP_BIG; }
+// One bounce of camera.rs:274-304 as the per-channel map x -> w x (specular, camera.rs:274-276: klo = -CHIP_BIG) or
+// x -> clamp(w x, 0, khi) (the PDF branch, camera.rs:304: klo = 0), composed on the right of the path's map.  The image of
+// [0, khi] under x -> b x is the interval between 0 and b khi, clipped by the clamp the path already carries.
 __device__ inline void affine_compose(Affine& f, const float w[3], float klo, float khi) {
+  const bool clamps = klo > -CHIP_BIG;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
-    float p = f.b[c] * klo, q = f.b[c] * khi;
-    float nlo = fclampf(p < q ? p : q, f.lo[c], f.hi[c]);
-    float nhi = fclampf(p < q ? q : p, f.lo[c], f.hi[c]);
+    if (clamps) f.bound[c] = fclampf(f.b[c] * khi, affine_lo(f, c), affine_hi(f, c));
     f.b[c] = f.b[c] * w[c];
-    f.lo[c] = nlo;
-    f.hi[c] = nhi;
   }
+  if (clamps) f.clamped = CHIP_MAP_CLAMPED;
+}
+__device__ inline float affine_apply(const Affine& f, int c, float x) {
+  const float v = f.b[c] * x;
+  return f.clamped ? fclampf(v, fminf(0.f, f.bound[c]), fmaxf(0.f, f.bound[c])) : v;
 }
 __device__ inline void finish_path(const PathPool& P, uint32_t slot, const Affine& f, const float x[3]) {
-  P.sample[slot] = make_float4(fclampf(f.b[0] * x[0], f.lo[0], f.hi[0]), fclampf(f.b[1] * x[1], f.lo[1], f.hi[1]),
-                               fclampf(f.b[2] * x[2], f.lo[2], f.hi[2]), 0.f);
+  // (the id travelled through memory: one that does not name a slot of the pool is reported, not written through)
+  if (slot < P.cap) P.sample[slot] = make_float4(affine_apply(f, 0, x[0]), affine_apply(f, 1, x[1]), affine_apply(f, 2, x[2]), 0.f);
+  else atomicOr(&P.errflag[1], 1u);
 }
 // 16-byte accesses of a ray record
 __device__ inline void ray_load(const PathRay* rec, V3& o, V3& d, double& time, uint32_t& id) {
@@ -1445,6 +1458,7 @@ template <int STRIDE, int NCH>
 __device__ inline void quad_load(const void* base, uint32_t slot, uint32_t lane, uint4* stage, QuadRecord& r) {
   const uint32_t c = lane & 3, q = lane >> 2;
   uint32_t s[4] = {quad_bcast<0>(slot), quad_bcast<1>(slot), quad_bcast<2>(slot), quad_bcast<3>(slot)};
+  asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));  // (keeps the cross-lane reads here, where every lane is active: see quad_pair_slots)
   uint4 v[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -1468,6 +1482,7 @@ template <int STRIDE, int NCH>
 __device__ inline void quad_load_issue(const void* base, uint32_t slot, uint32_t lane, uint4 (&v)[4]) {
   const uint32_t c = lane & 3;
   uint32_t s[4] = {quad_bcast<0>(slot), quad_bcast<1>(slot), quad_bcast<2>(slot), quad_bcast<3>(slot)};
+  asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));  // (keeps the cross-lane reads here, where every lane is active: see quad_pair_slots)
   // (each load under its own condition, as in quad_load: measured faster than loads without branches, and the
   // branches keep the compiler from moving the loads down to their first use)
 #pragma unroll
@@ -1501,6 +1516,7 @@ __device__ inline void quad_store(void* base, uint32_t slot, uint32_t lane, uint
   for (int k = 0; k < NCH; k++) stage[own + k] = make_uint4(r.w[k][0], r.w[k][1], r.w[k][2], r.w[k][3]);
   __builtin_amdgcn_wave_barrier();
   uint32_t s[4] = {quad_bcast<0>(slot), quad_bcast<1>(slot), quad_bcast<2>(slot), quad_bcast<3>(slot)};
+  asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));  // (keeps the cross-lane reads here, where every lane is active: see quad_pair_slots)
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     if (s[j] != CHIP_NO_SLOT && (NCH == 4 || c < NCH))
@@ -1508,6 +1524,58 @@ __device__ inline void quad_store(void* base, uint32_t slot, uint32_t lane, uint
   }
   __builtin_amdgcn_wave_barrier();
 }
+// The same for 32-byte records (two chunks): one instruction moves two records per quad, lanes 0 and 1 of the quad the
+// chunks of one, lanes 2 and 3 those of the next, so two instructions instead of four cover the wave.
+// The slots of the two records a lane helps to move: those of quad lanes 0 and 2 for the lower half of the quad, of quad
+// lanes 1 and 3 for the upper half.  All four cross-lane reads happen here, with every lane of the wave active, and the
+// empty asm pins them to this point: written as `upper ? quad_bcast<1>(slot) : quad_bcast<0>(slot)` the compiler turns the
+// selection into branches and moves each read into its branch, where the lane it reads from is switched off and reads as 0.
+__device__ inline void quad_pair_slots(uint32_t slot, bool upper, uint32_t& s0, uint32_t& s1) {
+  uint32_t b0 = quad_bcast<0>(slot), b1 = quad_bcast<1>(slot), b2 = quad_bcast<2>(slot), b3 = quad_bcast<3>(slot);
+  asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+  s0 = upper ? b1 : b0;
+  s1 = upper ? b3 : b2;
+}
+__device__ inline void quad_load32_issue(const void* base, uint32_t slot, uint32_t lane, uint4 (&v)[2]) {
+  const uint32_t c = lane & 1u, hi = lane & 2u;
+  uint32_t s0, s1;
+  quad_pair_slots(slot, hi != 0u, s0, s1);
+  v[0] = make_uint4(0, 0, 0, 0);
+  v[1] = make_uint4(0, 0, 0, 0);
+  if (s0 != CHIP_NO_SLOT) v[0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + (size_t)s0 * 32 + c * 16);
+  if (s1 != CHIP_NO_SLOT) v[1] = *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + (size_t)s1 * 32 + c * 16);
+}
+__device__ inline void quad_load32_finish(const uint4 (&v)[2], uint32_t lane, uint4* stage, QuadRecord& r) {
+  const uint32_t c = lane & 1u, m = (lane >> 1) & 1u, q = lane >> 2;
+  stage[xpose_at(16u * m + q) + c] = v[0];
+  stage[xpose_at(16u * (2u + m) + q) + c] = v[1];
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t own = xpose_at(16u * (lane & 3u) + q);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint4 t = stage[own + k];
+    r.w[k][0] = t.x; r.w[k][1] = t.y; r.w[k][2] = t.z; r.w[k][3] = t.w;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ inline void quad_load32(const void* base, uint32_t slot, uint32_t lane, uint4* stage, QuadRecord& r) {
+  uint4 v[2];
+  quad_load32_issue(base, slot, lane, v);
+  quad_load32_finish(v, lane, stage, r);
+}
+__device__ inline void quad_store32(void* base, uint32_t slot, uint32_t lane, uint4* stage, const QuadRecord& r) {
+  const uint32_t c = lane & 1u, hi = lane & 2u, m = (lane >> 1) & 1u, q = lane >> 2;
+  const uint32_t own = xpose_at(16u * (lane & 3u) + q);
+#pragma unroll
+  for (int k = 0; k < 2; k++) stage[own + k] = make_uint4(r.w[k][0], r.w[k][1], r.w[k][2], r.w[k][3]);
+  __builtin_amdgcn_wave_barrier();
+  uint32_t s0, s1;
+  quad_pair_slots(slot, hi != 0u, s0, s1);
+  if (s0 != CHIP_NO_SLOT) *reinterpret_cast<uint4*>(static_cast<char*>(base) + (size_t)s0 * 32 + c * 16) = stage[xpose_at(16u * m + q) + c];
+  if (s1 != CHIP_NO_SLOT) *reinterpret_cast<uint4*>(static_cast<char*>(base) + (size_t)s1 * 32 + c * 16) = stage[xpose_at(16u * (2u + m) + q) + c];
+  __builtin_amdgcn_wave_barrier();
+}
+static_assert(sizeof(PathMap) == 32, "the 32-byte record accessors move the radiance map");
 __device__ inline void d2u(double v, uint32_t& lo, uint32_t& hi) {
   lo = (uint32_t)__double2loint(v);
   hi = (uint32_t)__double2hiint(v);
@@ -1525,19 +1593,18 @@ __device__ inline void ray_pack(QuadRecord& q, V3 o, V3 d, double time, uint32_t
   d2u(time, q.w[3][0], q.w[3][1]); q.w[3][2] = id; q.w[3][3] = 0;
 }
 __device__ inline void affine_unpack(const QuadRecord& q, Affine& f, uint32_t& id) {
-  id = q.w[0][0]; f.b[0] = __uint_as_float(q.w[0][3]);
-  f.b[1] = __uint_as_float(q.w[1][0]); f.b[2] = __uint_as_float(q.w[1][1]); f.lo[0] = __uint_as_float(q.w[1][2]); f.lo[1] = __uint_as_float(q.w[1][3]);
-  f.lo[2] = __uint_as_float(q.w[2][0]); f.hi[0] = __uint_as_float(q.w[2][1]); f.hi[1] = __uint_as_float(q.w[2][2]); f.hi[2] = __uint_as_float(q.w[2][3]);
+  id = q.w[0][0] & ~CHIP_MAP_CLAMPED; f.clamped = q.w[0][0] & CHIP_MAP_CLAMPED;
+  f.b[0] = __uint_as_float(q.w[0][1]); f.b[1] = __uint_as_float(q.w[0][2]); f.b[2] = __uint_as_float(q.w[0][3]);
+  f.bound[0] = __uint_as_float(q.w[1][0]); f.bound[1] = __uint_as_float(q.w[1][1]); f.bound[2] = __uint_as_float(q.w[1][2]);
 }
 __device__ inline void affine_pack(QuadRecord& q, const Affine& f, uint32_t id) {
-  q.w[0][0] = id; q.w[0][1] = 0u; q.w[0][2] = 0u; q.w[0][3] = __float_as_uint(f.b[0]);
-  q.w[1][0] = __float_as_uint(f.b[1]); q.w[1][1] = __float_as_uint(f.b[2]); q.w[1][2] = __float_as_uint(f.lo[0]); q.w[1][3] = __float_as_uint(f.lo[1]);
-  q.w[2][0] = __float_as_uint(f.lo[2]); q.w[2][1] = __float_as_uint(f.hi[0]); q.w[2][2] = __float_as_uint(f.hi[1]); q.w[2][3] = __float_as_uint(f.hi[2]);
-  q.w[3][0] = 0; q.w[3][1] = 0; q.w[3][2] = 0; q.w[3][3] = 0;
+  q.w[0][0] = id | f.clamped; q.w[0][1] = __float_as_uint(f.b[0]); q.w[0][2] = __float_as_uint(f.b[1]); q.w[0][3] = __float_as_uint(f.b[2]);
+  q.w[1][0] = __float_as_uint(f.bound[0]); q.w[1][1] = __float_as_uint(f.bound[1]); q.w[1][2] = __float_as_uint(f.bound[2]); q.w[1][3] = 0u;
 }
 __device__ inline void affine_identity(Affine& f) {
 #pragma unroll
-  for (int c = 0; c < 3; c++) { f.b[c] = 1.f; f.lo[c] = -CHIP_BIG; f.hi[c] = CHIP_BIG; }
+  for (int c = 0; c < 3; c++) { f.b[c] = 1.f; f.bound[c] = 0.f; }
+  f.clamped = 0u;
 }
 // The radiance map of every lane's entry of `bounce` (the identity before the first bounce, never stored).
 template <bool B0>
@@ -1547,7 +1614,7 @@ __device__ inline void quad_load_map(const PathPool& P, uint32_t entry, uint32_t
     id = entry;  // at bounce 0 entry i is path i
   } else {
     QuadRecord q;
-    quad_load<(int)sizeof(PathMap), 3>(P.st[bounce & 1], entry, lane, stage, q);
+    quad_load32(P.st[bounce & 1], entry, lane, stage, q);
     affine_unpack(q, f, id);
   }
 }
@@ -2298,13 +2365,13 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
          travel while it chases the hit's sphere and material records (one memory round trip less per trip).  The \
          other forms load the map after the material code, which is where their registers are scarce. */         \
       constexpr bool EARLY_MAP = LEAN && FAST && !B0;                                                            \
-      uint4 mapv[4];                                                                                             \
-      if (EARLY_MAP) quad_load_issue<(int)sizeof(PathMap), 3>(P.st[bounce & 1], entry, lane, mapv);              \
+      uint4 mapv[2];                                                                                             \
+      if (EARLY_MAP) quad_load32_issue(P.st[bounce & 1], entry, lane, mapv);                                     \
       if (valid) cont = shade_hit<KIND, FAST, LEAN, EXT, PLAIN>(S, B, bounce, id, ph, ro, rd, rtime, xw, klo, khi, no, nd); \
       Affine f;                                                                                                  \
       if (EARLY_MAP) {                                                                                           \
         QuadRecord qm;                                                                                           \
-        quad_load_finish<3>(mapv, lane, stage, qm);                                                              \
+        quad_load32_finish(mapv, lane, stage, qm);                                                                \
         affine_unpack(qm, f, id);                                                                                \
       } else {                                                                                                   \
         quad_load_map<B0>(P, entry, lane, bounce, stage, f, id);                                                 \
@@ -2324,7 +2391,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
         ray_pack(q, no, nd, rtime, id);                                                                          \
         quad_store<(int)sizeof(PathRay), 4>(ray_out, out, lane, stage, q);                                            \
         affine_pack(q, f, id);                                                                                   \
-        quad_store<(int)sizeof(PathMap), 3>(st_out, out, lane, stage, q);                                             \
+        quad_store32(st_out, out, lane, stage, q);                                        \
       }                                                                                                          \
     }                                                                                                            \
   }
