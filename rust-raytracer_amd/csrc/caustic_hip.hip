@@ -121,6 +121,7 @@ struct PoolBufs {
   DevBuf<float4> sample;
   DevBuf<uint32_t> qlit, counters, ovf;
   uint32_t counters_rows = 0;
+  size_t slack = 0;  // entries the per-bounce arrays hold beyond P.cap (see PathPool::slack)
   void release() {
     ray.release(); hit.release(); st.release(); sample.release();
     qlit.release(); counters.release(); ovf.release();
@@ -259,7 +260,8 @@ static size_t pool_capacity_max() {
   }
   return (size_t)1 << 28;
 }
-static const size_t kBytesPerPathSlot = 2 * sizeof(PathRay) + sizeof(PathHit) + 2 * sizeof(PathMap) + sizeof(float4) + sizeof(uint32_t);
+// (per-bounce arrays hold 1/16 more entries than the pool has path slots: PathPool::slack)
+static const size_t kBytesPerPathSlot = (2 * sizeof(PathRay) + sizeof(PathHit) + 2 * sizeof(PathMap) + sizeof(uint32_t)) * 17 / 16 + sizeof(float4);
 
 // The small per-device resources of a scene (with the device current): streams, events, pinned words, error and
 // statistics words, and the address of this device's copy of the no-allocation scratch.
@@ -292,6 +294,7 @@ static int ensure_resources(DeviceState& D) {
     P.hit = L->hit; P.sample = L->sample; P.q_lit = L->qlit;
     P.counters = L->counters; P.errflag = L->err; P.stats = L->stats; P.ovf = L->ovf;
     P.cap = CHIP_NOALLOC_PATHS;
+    P.slack = 0;
     P.ovf_slabs = CHIP_NOALLOC_OVF_SLABS;
   }
   D.res_ready = true;
@@ -319,19 +322,22 @@ static int ensure_pool(const chip_scene* s, DeviceState& D, int which, size_t wa
     pb.ray.release(); pb.hit.release(); pb.st.release(); pb.sample.release();
     pb.qlit.release();
     pb.ready = false;
-    HIP_TRY(pb.ray.alloc(2 * cap));
-    HIP_TRY(pb.hit.alloc(cap));
-    HIP_TRY(pb.st.alloc(2 * cap));
+    // the arrays indexed by a bounce's entries have room for the empty entries a bounce may hold beside its live paths
+    pb.slack = cap / 16;
+    HIP_TRY(pb.ray.alloc(2 * (cap + pb.slack)));
+    HIP_TRY(pb.hit.alloc(cap + pb.slack));
+    HIP_TRY(pb.st.alloc(2 * (cap + pb.slack)));
     HIP_TRY(pb.sample.alloc(cap));
-    HIP_TRY(pb.qlit.alloc(cap));
+    HIP_TRY(pb.qlit.alloc(cap + pb.slack));
     pb.P.cap = (uint32_t)cap;
+    pb.P.slack = (uint32_t)pb.slack;
   }
   if (pb.counters_rows < rows) {
     HIP_TRY(pb.counters.alloc((size_t)rows * CHIP_CTR_STRIDE));
     pb.counters_rows = rows;
   }
   PathPool& P = pb.P;
-  P.ray[0] = pb.ray.p; P.ray[1] = pb.ray.p + P.cap; P.st[0] = pb.st.p; P.st[1] = pb.st.p + P.cap;
+  P.ray[0] = pb.ray.p; P.ray[1] = pb.ray.p + (P.cap + pb.slack); P.st[0] = pb.st.p; P.st[1] = pb.st.p + (P.cap + pb.slack);
   P.hit = pb.hit.p; P.sample = pb.sample.p; P.q_lit = pb.qlit.p;
   P.counters = pb.counters.p; P.errflag = D.p_err.p; P.stats = D.p_stats.p; P.ovf = pb.ovf.p;
   P.ovf_slabs = kMaxGridBlocks * CHIP_BLOCK;
@@ -490,6 +496,35 @@ static int launch_extend_small(const DeviceState& D, const PathPool& P, const Ex
   hipLaunchKernelGGL((k_extend_small<B0>), dim3(blocks), dim3(p.block), p.lds_bytes, st, D.dscene, P, B, bounce, p.cd);
   return 0;
 }
+// Bounce 0 of a small sphere scene with lean shading, traced and shaded by one kernel (k_first_small).
+// waste_out: upper bound on the empty entries the launch may leave in bounce 1's arrays.
+static int launch_first_small(const DeviceState& D, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
+                              bool fast, uint32_t* waste_out) {
+  static std::atomic<uint64_t> attr_done{0};
+  const uint64_t bit = 1ull << ((unsigned)D.device & 63u);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_first_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_first_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  if (p.block != (uint32_t)extend_block(0, true)) return fail("internal: traversal launch planned for another kernel variant");
+  uint32_t blocks = (n_live_upper + p.block - 1) / p.block;
+  blocks = std::max(1u, std::min(blocks, (uint32_t)D.n_cus));
+  // Entries of bounce 1 are handed to the waves in ranges (one atomic per range); every wave may leave part of its last
+  // range empty, so the ranges are sized to keep that within the slack the pool's arrays have beyond `cap` entries.
+  // Small launches take exactly what they need per wave and trip.
+  const uint32_t n_waves = blocks * (p.block / 64u);
+  uint32_t range = 0;
+  if (n_live_upper >= (1u << 22) && P.slack >= n_live_upper / 16u) {
+    range = (n_live_upper / (n_waves * 16u)) & ~63u;
+    range = std::min(range, 2048u);
+    if (range < 64u) range = 0;
+  }
+  *waste_out = range * n_waves;
+  if (fast) hipLaunchKernelGGL((k_first_small<true>), dim3(blocks), dim3(p.block), p.lds_bytes, st, D.dscene, P, B, p.cd, range);
+  else hipLaunchKernelGGL((k_first_small<false>), dim3(blocks), dim3(p.block), p.lds_bytes, st, D.dscene, P, B, p.cd, range);
+  return 0;
+}
 template <uint32_t F, bool CACHE, bool ORD>
 static int launch_extend_t(const DeviceState& D, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
                            uint32_t bounce, uint32_t lit_pass) {
@@ -528,8 +563,9 @@ static ExtendPlans plan_extends(const chip_scene* s, uint32_t scene_feat) {
 // them in a reference_order render).
 // lit_expected: whether the literal queue is expected to hold rays (it sizes the literal pass's grid only: one block
 // drains a queue of any length, slowly).
+// fused_first (bounce 0 only; 0 = off, 1 = exact shading, 2 = fast shading): the traversal kernel also shades its hits.
 static int launch_extend(const DeviceState& D, const PathPool& P, const ExtendPlans& X, uint32_t n_live_upper, hipStream_t st,
-                         const BatchDesc& B, uint32_t bounce, bool lit_expected) {
+                         const BatchDesc& B, uint32_t bounce, bool lit_expected, int fused_first = 0, uint32_t* waste_out = nullptr) {
   const uint32_t feat = X.feat;
   const ExtendPlan& lit = X.lit;
   const ExtendPlan& p = n_live_upper < X.small_queue ? X.shortq : X.full;
@@ -540,6 +576,12 @@ static int launch_extend(const DeviceState& D, const PathPool& P, const ExtendPl
                       : launch_extend_t<FEAT, false, true>(D, P, p, n_live_upper, st, B, bounce, 0);     \
     if (rc_) return rc_;                                                                                 \
     return launch_extend_t<FEAT, false, false>(D, P, lit, lit_upper, st, B, bounce, 1);                  \
+  }
+  if (fused_first) {
+    if (!(bounce == 0 && feat == 0 && X.full.cache && X.full.small) || !waste_out) return fail("internal: fused first bounce planned for a scene it does not cover");
+    int rc_ = launch_first_small(D, P, X.full, n_live_upper, st, B, fused_first == 2, waste_out);
+    if (rc_) return rc_;
+    return launch_extend_t<0, false, false>(D, P, lit, lit_upper, st, B, bounce, 1);
   }
   if (feat == 0 && p.cache && p.small) {
     int rc_ = bounce == 0 ? launch_extend_small<true>(D, P, p, n_live_upper, st, B, bounce) : launch_extend_small<false>(D, P, p, n_live_upper, st, B, bounce);
@@ -580,6 +622,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   const bool exact_shading = (o->flags & CHIP_RENDER_EXACT_SHADING) != 0 || s->flat.nonunit_normals != 0;
   const uint32_t feat = scene_features(s->flat);
   const ExtendPlans xplans = plan_extends(s, feat);
+  const bool no_fused_first = [] { const char* e = getenv("CHIP_NO_FUSED_FIRST"); return e && *e == '1'; }();  // (per call: tests compare both forms)
   // spheres with solid colours and no light sampling: the lean shade kernels
   bool solid_only = !s->flat.has_lights;
   for (const DTexture& t : s->host.textures) solid_only = solid_only && t.kind == TK_SOLID;
@@ -588,6 +631,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   // solid colours and checkers only: the full shade kernel without its image / noise texture code
   bool plain_textures = true;
   for (const DTexture& t : s->host.textures) plain_textures = plain_textures && (t.kind == TK_SOLID || t.kind == TK_CHECKER);
+  const bool fused_first_ok = lean && xplans.feat == 0 && xplans.full.cache && xplans.full.small && !no_fused_first;
   const bool lean_xform = solid_only && (feat & ~TF_NO_QUADROT) == (TF_QUADS | TF_XFORM) && s->flat.quads.empty() && s->flat.media.empty();
 
   // pools: two when the render is large enough to be worth splitting
@@ -731,14 +775,21 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
     };
     while (L.bounce < cam.max_depth) {
       const uint32_t bounce = L.bounce;
-      const uint32_t grid = std::min(grid_for(L.live_upper), shade_grid_max);
+      const uint32_t grid_full = std::min(grid_for(L.live_upper), shade_grid_max);
       if (time_kernels && stamp()) return -1;
-      if (launch_extend(D, P, xplans, L.live_upper, L.st, B, bounce, L.lit_expected)) {
+      // bounce 0 of a small sphere scene with lean shading: one kernel traces and shades; the shade launch below then
+      // only takes the rays that went through the literal queue (normally none: one block)
+      const bool fused = bounce == 0 && fused_first_ok && !B.reference_order;
+      uint32_t waste = 0;
+      if (launch_extend(D, P, xplans, L.live_upper, L.st, B, bounce, L.lit_expected, fused ? (exact_shading ? 1 : 2) : 0, &waste)) {
         bag.failed = true;
         return -1;
       }
       if (time_kernels && stamp()) return -1;
       n_trace_launches++;
+      const uint32_t shade_pass_all = fused ? (uint32_t)SHADE_LIT_QUEUE : (uint32_t)SHADE_ALL;
+      const uint32_t grid = fused ? (L.lit_expected ? std::min(grid_full, 64u) : 1u) : grid_full;
+      if (fused) L.live_upper += waste;  // (bounce 1 may hold that many empty entries beside its paths)
       {
         const bool ext = (feat & TF_EXT) != 0;
 #define CHIP_SHADE(FAST, LEAN, EXT, PASS)                                                                                          \
@@ -754,7 +805,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
     else hipLaunchKernelGGL((k_shade_tiles<FAST, false, EXT, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
   } while (0)
         if (lean) {
-          if (exact_shading) CHIP_SHADE(false, true, false, SHADE_ALL); else CHIP_SHADE(true, true, false, SHADE_ALL);
+          if (exact_shading) CHIP_SHADE(false, true, false, shade_pass_all); else CHIP_SHADE(true, true, false, shade_pass_all);
         } else if (lean_xform) {
           if (exact_shading) CHIP_SHADE(false, true, true, SHADE_ALL); else CHIP_SHADE(true, true, true, SHADE_ALL);
         } else if (plain_textures) {

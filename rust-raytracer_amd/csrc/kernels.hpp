@@ -103,7 +103,8 @@ struct PathPool {
   uint32_t* errflag;    // [4]: [0] traversal stack overflow
   unsigned long long* stats;  // [4]: segments, bvh visits, prim tests, spare
   uint32_t* ovf;        // [ovf_slabs][2 * CHIP_STACK_OVF] traversal stack spill (value, distance pairs), one slab per thread of a launch
-  uint32_t cap;
+  uint32_t cap;         // path slots (what `sample` holds and a batch may hold paths)
+  uint32_t slack;       // entries the per-bounce arrays (ray, st, hit, q_lit) hold beyond cap: a bounce may carry empty entries beside its paths
   uint32_t ovf_slabs;
 };
 
@@ -2135,17 +2136,14 @@ __global__ void __launch_bounds__(extend_block(0, true), extend_min_waves(0, tru
 // LEAN is the variant for scenes made only of spheres with solid-colour textures and no lights (no
 // transforms, quads, media, image / noise / checker textures or light sampling to carry in registers);
 // LEAN with EXT is the same for spheres under Translate / Rotate instances.
+// shade_material: the material part, on a HitRecord the caller has built, with the path's random stream named by
+// (pixel, stratum); shade_hit: the same after rebuilding the HitRecord from (ray, t, node) and the path slot.
 template <uint32_t KIND, bool FAST, bool LEAN, bool EXT, bool PLAIN>
-__device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t bounce, uint32_t slot, const PathHit& ph, V3 ro, V3 rd,
-                                 double rtime, float (&xw)[3], float& klo_out, float& khi_out, V3& next_o, V3& next_d) {
+__device__ inline bool shade_material(const DScene& S, const BatchDesc& B, uint32_t bounce, uint32_t pixel, uint32_t stratum, const DMaterial& M,
+                                      const HitOut& hrec, V3 rd, float (&xw)[3], float& klo_out, float& khi_out, V3& next_o, V3& next_d) {
   bool cont = false;
   xw[0] = 0.f; xw[1] = 0.f; xw[2] = 0.f;
-  // HitRecord of the segment's closest hit (object/mod.rs:31-51), rebuilt from (ray, t, node)
-  const nref_t leaf = ph.node;
-  const DMaterial& M = S.materials[MATK_ID(ph.info)];
   const bool has_lights = !LEAN && S.has_lights;
-  HitOut hrec;
-  reconstruct<LEAN ? (EXT ? TF_XFORM : 0u) : (TF_QUADS | TF_XFORM | TF_MEDIA | (EXT ? TF_EXT : 0u)), FAST>(S, leaf, ph.t, ro, rd, rtime, hrec, !LEAN && !PLAIN && (M.flags & MF_NEEDS_UV) != 0);
   const bool front = hrec.front;
   const V3 pt = hrec.pt;
   if (KIND == MK_DIFFUSE_LIGHT) {
@@ -2158,8 +2156,6 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
     // empty.rs:18-27 + default emitted: zero radiance
   } else {
     const V3 nrm = hrec.n;
-    uint32_t x_, y_, pixel, stratum;
-    slot_to_path(B, S.cam, slot, x_, y_, pixel, stratum);
     Rng rng;
     rng.init(B.seed_lo, B.seed_hi, pixel, stratum, bounce, 0);  // (the traversal draws nothing from the stream: media samples are keyed)
     V3 ndir;
@@ -2266,6 +2262,17 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
   }
   return cont;
 }
+template <uint32_t KIND, bool FAST, bool LEAN, bool EXT, bool PLAIN>
+__device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t bounce, uint32_t slot, const PathHit& ph, V3 ro, V3 rd,
+                                 double rtime, float (&xw)[3], float& klo_out, float& khi_out, V3& next_o, V3& next_d) {
+  // HitRecord of the segment's closest hit (object/mod.rs:31-51), rebuilt from (ray, t, node)
+  const DMaterial& M = S.materials[MATK_ID(ph.info)];
+  HitOut hrec;
+  reconstruct<LEAN ? (EXT ? TF_XFORM : 0u) : (TF_QUADS | TF_XFORM | TF_MEDIA | (EXT ? TF_EXT : 0u)), FAST>(S, ph.node, ph.t, ro, rd, rtime, hrec, !LEAN && !PLAIN && (M.flags & MF_NEEDS_UV) != 0);
+  uint32_t x_ = 0, y_ = 0, pixel = 0, stratum = 0;
+  if (KIND != MK_DIFFUSE_LIGHT && KIND != MK_EMPTY) slot_to_path(B, S.cam, slot, x_, y_, pixel, stratum);
+  return shade_material<KIND, FAST, LEAN, EXT, PLAIN>(S, B, bounce, pixel, stratum, M, hrec, rd, xw, klo_out, khi_out, next_o, next_d);
+}
 
 // Material-binned shading of one bounce.  A block takes a tile of the bounce's entries, bins them by the
 // material kind of their hit in LDS (a counting sort; misses and empty entries last), and shades the tile
@@ -2277,7 +2284,10 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
 // B0: the instantiation for bounce 0, whose entries are the batch's paths in order with their camera rays
 // recomputed and the identity as radiance map; kept apart so that neither variant pays registers for the other.
 // `pass`: which entries of the bounce this launch shades.
-enum : uint32_t { SHADE_ALL = 0, SHADE_PLAIN_ONLY = 1, SHADE_RICH_ONLY = 2 };
+// SHADE_LIT_QUEUE (bounce 0 only): the entries are those the literal queue of the bounce names, for the form of bounce 0
+// in which the traversal kernel shades its own hits (k_first_small) and only the rays it handed to the literal pass are
+// left.
+enum : uint32_t { SHADE_ALL = 0, SHADE_PLAIN_ONLY = 1, SHADE_RICH_ONLY = 2, SHADE_LIT_QUEUE = 3 };
 template <bool FAST, bool LEAN, bool EXT, bool B0, bool PLAIN = false>
 __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_WAVES : (LEAN ? 1 : (PLAIN ? CHIP_SHADE_PLAIN_WAVES : CHIP_SHADE_FULL_WAVES))) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg, uint32_t pass) {
   const uint32_t bounce = B0 ? 0u : bounce_arg;
@@ -2289,7 +2299,8 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
   PathMap* st_out = P.st[(bounce + 1) & 1];
   uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
   uint32_t* ctr_next = P.counters + (size_t)(bounce + 1) * CHIP_CTR_STRIDE;
-  const uint32_t n_live = ctr[0];
+  const bool via_queue = B0 && pass == SHADE_LIT_QUEUE;  // entry i of this launch is q_lit[i]
+  const uint32_t n_live = via_queue ? ctr[CHIP_CTR_LIT] : ctr[0];
   const bool last_bounce = bounce + 1 >= S.cam.max_depth;
   constexpr uint32_t NB = MK_COUNT + 3;        // material kinds, misses, empty entries, entries left to the other pass
   __shared__ uint16_t s_order[CHIP_SHADE_TILE];  // tile-local entry numbers, sorted by bin
@@ -2309,9 +2320,10 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
     __syncthreads();
     const uint32_t tile_n = min(tile, n_live - tile0);
     for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) {
-      const uint2 hw = *reinterpret_cast<const uint2*>(&P.hit[tile0 + k].node);
+      const uint32_t e = via_queue ? P.q_lit[tile0 + k] : tile0 + k;
+      const uint2 hw = *reinterpret_cast<const uint2*>(&P.hit[e].node);
       uint32_t kind = hw.x == NREF_NONE ? MK_COUNT : (hw.x == NREF_DEAD ? MK_COUNT + 1 : MATK_KIND(hw.y));
-      if (pass != SHADE_ALL) {
+      if (pass == SHADE_PLAIN_ONLY || pass == SHADE_RICH_ONLY) {
         // two launches share the bounce: hits on materials with an image / noise texture go to the second one (the
         // full kernel), everything else, misses included, to the first (the kernel without that code)
         const bool rich = kind < MK_COUNT && (S.materials[MATK_ID(hw.y)].flags & MF_RICH_TEX) != 0;
@@ -2343,7 +2355,8 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
     for (uint32_t k0 = __builtin_amdgcn_readfirstlane(s_off[KIND] + (threadIdx.x & ~63u)); k0 < bin_end; k0 += CHIP_BLOCK) { \
       const uint32_t k = k0 + lane_entry;                                                                        \
       const bool valid = k < bin_end;                                                                            \
-      const uint32_t entry = valid ? tile0 + s_order[k] : CHIP_NO_SLOT;                                          \
+      uint32_t entry = valid ? tile0 + s_order[k] : CHIP_NO_SLOT;                                                \
+      if (via_queue && valid) entry = P.q_lit[entry];                                                            \
       PathHit ph;                                                                                                \
       ph.t = 0.0; ph.node = NREF_NONE; ph.info = 0;                                                              \
       if (valid) *reinterpret_cast<uint4*>(&ph) = *reinterpret_cast<const uint4*>(P.hit + entry);                \
@@ -2407,7 +2420,8 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
       for (uint32_t k0 = __builtin_amdgcn_readfirstlane(s_off[MK_COUNT] + (threadIdx.x & ~63u)); k0 < bin_end; k0 += CHIP_BLOCK) {
         const uint32_t k = k0 + lane_entry;
         const bool valid = k < bin_end;
-        const uint32_t entry = valid ? tile0 + s_order[k] : CHIP_NO_SLOT;
+        uint32_t entry = valid ? tile0 + s_order[k] : CHIP_NO_SLOT;
+        if (via_queue && valid) entry = P.q_lit[entry];
         uint32_t id = entry;
         Affine f;
         quad_load_map<B0>(P, entry, lane, bounce, stage, f, id);  // a miss needs nothing of its ray record
@@ -2420,6 +2434,222 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
     for (uint32_t k = s_live + threadIdx.x; k < s_reserved; k += CHIP_BLOCK)
       reinterpret_cast<uint4*>(ray_out + s_base + k)[3] = make_uint4(0u, 0u, CHIP_DEAD_ID, 0u);
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ bounce 0 in one kernel (small sphere scenes)
+// Camera rays of one wave come from an 8 x 8 pixel tile: they finish their traversal at about the same time and mostly
+// hit the same few spheres, so the wave-at-a-time form loses little to divergence, and shading them where they were
+// traced saves what the two-kernel form pays at bounce 0: the hit record's trip through memory, the second evaluation of
+// the camera ray (three to six Philox blocks) and the binning pass.  k_first_small is k_extend_small<true> followed, per
+// wave, by the lean shade code (spheres with solid colours, no lights) on the 64 hits; the paths that go on write their
+// ray and radiance map as entries of bounce 1.  Rays the compact traversal does not take (a zero direction component,
+// a descent deeper than its stack) go to the literal queue as before; the literal pass traces them and one launch of the
+// bounce-0 shade kernel over that queue (SHADE_LIT_QUEUE) shades them with the same code.
+//
+// Entries of bounce 1 are handed out to the waves in ranges of `out_range` entries taken from the bounce's entry counter
+// (one atomic per range instead of one per wave and trip); a wave's outputs fill its range from the front, the next
+// range is taken when one is used up (an output run may straddle two ranges), and what is left of a wave's last range
+// when the kernel ends is marked empty, like the entries the shade kernel reserves for paths that then end.  With
+// out_range = 0 a wave takes exactly what it needs per trip (small launches, where the counter is not contended and
+// the pool has no room to spare).
+template <bool FAST>
+__global__ void __launch_bounds__(extend_block(0, true), 4) k_first_small(DScene S, PathPool P, BatchDesc B, CacheDesc cd, uint32_t out_range) {
+  const NodeCache C{0u, (uint32_t)CHIP_WNODE_U4 * cd.n_bvh, cd.n_bvh, cd.n_sph, cd.n_bvh, cd.n_sph};
+  uint32_t* ctr = P.counters;
+  uint32_t* ctr_next = P.counters + CHIP_CTR_STRIDE;
+  const uint32_t n_live = ctr[0];
+  if ((size_t)blockIdx.x * 64u >= n_live) return;
+  for (uint32_t i = threadIdx.x; i < cd.n_bvh; i += blockDim.x) {
+    const uint4* p = reinterpret_cast<const uint4*>(S.wnodes + i);
+#pragma unroll
+    for (int k = 0; k < 6; k++) g_lds[(uint32_t)CHIP_WNODE_U4 * i + k] = p[k];
+    const uint4 ch = p[6];
+    g_lds[(uint32_t)CHIP_WNODE_U4 * i + 6u] = make_uint4(small_ref(ch.x), small_ref(ch.y), small_ref(ch.z), small_ref(ch.w));
+  }
+  const uint32_t so = (uint32_t)CHIP_WNODE_U4 * cd.n_bvh;
+  for (uint32_t i = threadIdx.x; i < cd.n_sph; i += blockDim.x) {
+    const uint4* p = reinterpret_cast<const uint4*>(S.spheres + i);
+    g_lds[so + i] = p[0]; g_lds[so + cd.n_sph + i] = p[1]; g_lds[so + 2 * cd.n_sph + i] = p[2]; g_lds[so + 3 * cd.n_sph + i] = p[3];
+  }
+  __syncthreads();
+  uint32_t* cursor = &ctr[CHIP_CTR_CURSOR];
+  const uint32_t lane = __lane_id();
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  SmallStack st;
+  st.lds = (lds_u1_t)(g_lds + (CHIP_WNODE_U4 * cd.n_bvh + 4u * cd.n_sph)) + threadIdx.x;
+  st.overflow = 0;
+  st.sp = 0;
+  st.lds_cap = (int)cd.stack_entries;
+  st.stride4 = 4u * blockDim.x;
+  TravCounters cnt{0, 0};
+  uint32_t nseg = 0;
+  const uint32_t root = small_ref(S.ord_root);
+  const uint32_t n_waves = gridDim.x * (blockDim.x / 64);
+  uint32_t chunk = (n_live / (n_waves * 4u)) & ~63u;
+  chunk = chunk < 64u ? 64u : (chunk > 2048u ? 2048u : chunk);
+  uint32_t w_next = 0, w_end = 0;                // wave-uniform: the chunk of bounce-0 entries (= paths) in hand
+  uint32_t o_next = 0, o_end = 0;                // wave-uniform: the range of bounce-1 entries in hand
+  const bool last_bounce = 1u >= S.cam.max_depth;  // camera.rs:259-261
+  PathRay* ray_out = P.ray[1];
+  PathMap* st_out = P.st[1];
+  for (;;) {
+    if (w_next >= w_end) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(cursor, chunk);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base >= n_live) break;
+      w_next = base;
+      w_end = min(base + chunk, n_live);
+    }
+    // 1. the next 64 paths of the chunk, one per lane: camera ray (camera.rs:359-374)
+    const uint32_t entry = w_next + lane;
+    const bool mine = entry < w_end;
+    w_next = min(w_next + 64u, w_end);
+    TravRay r;
+    r.wo = r.wd = r.o = r.d = r.inv = mk(0, 0, 0);
+    r.time = 0;
+    r.best_mat = 0;
+    uint32_t pixel = 0, stratum = 0;
+    bool has = false;
+    double best_t = INFINITY;
+    nref_t best = NREF_NONE;
+    uint32_t node = CHIP_SM_NONE;
+    bool to_literal = false;
+    if (mine) {
+      uint32_t x, y;
+      slot_to_path(B, S.cam, entry, x, y, pixel, stratum);
+      Rng rng;
+      rng.init(B.seed_lo, B.seed_hi, pixel, stratum, CHIP_CAMERA_BOUNCE, 0);
+      const uint32_t s_y = magic_div(stratum, B.sqrt_spp_magic), s_x = stratum - s_y * S.cam.sqrt_spp;
+      uint32_t tries = 0;
+      camera_ray(S.cam, rng, x, y, s_x, s_y, r.wo, r.wd, r.time, tries);
+      r.o = r.wo; r.d = r.wd;
+      const bool ordinary = ray_set_inv<true>(r);
+#ifdef CHIP_TEST_HAND_OVER
+      to_literal = B.reference_order || !ordinary || entry % CHIP_TEST_HAND_OVER == 0u;
+#else
+      to_literal = B.reference_order || !ordinary;
+#endif
+      if (!to_literal) {
+        r.capf = INFINITY;
+        node = root;
+        st.sp = 0;
+        has = true;
+      }
+    }
+    // 2. closest hit; the whole wave stays until its last ray is done
+    if (has) traverse_small<true>(S, C, node, r, 0.001, best_t, best, st, cnt, 0);
+    if (has && st.overflow) {  // the descent ran out of stack: the literal pass traces this ray
+      st.overflow = 0;
+      has = false;
+      to_literal = true;
+    }
+    {
+      const unsigned long long ml = __ballot(to_literal);
+      if (ml) {
+        uint32_t lbase = 0;
+        if (lane == 0) lbase = atomicAdd(&ctr[CHIP_CTR_LIT], (uint32_t)__popcll(ml));
+        lbase = __builtin_amdgcn_readfirstlane(lbase);
+        if (to_literal) P.q_lit[lbase + (uint32_t)__popcll(ml & lanes_below)] = entry;
+      }
+    }
+    nseg += has ? 1u : 0u;
+    // 3. shading (material/*.rs through shade_material; a miss takes the background, camera.rs:264-266)
+    const uint32_t kind = !has ? 0xFFu : (best == NREF_NONE ? (uint32_t)MK_COUNT : MATK_KIND(r.best_mat));
+    float xw[3] = {0.f, 0.f, 0.f}, klo = 0.f, khi = 0.f;
+    bool cont = false;
+    V3 no = mk(0, 0, 0), nd = mk(0, 0, 0);
+    HitOut hrec;
+    hrec.pt = hrec.n = mk(0, 0, 0);
+    hrec.u = hrec.v = 0.0;
+    hrec.front = false;
+    hrec.mat = 0;
+    hrec.leaf_id = -1;
+    if (has && best != NREF_NONE) {
+      // HitRecord of the closest sphere (sphere.rs:122-134, object/mod.rs:44-51) from its LDS copy; the same arithmetic as
+      // reconstruct<0, FAST>, which the shade kernel runs for the rays the literal pass traced
+      const uint32_t i = C.sph_off + NREF_INDEX(best);
+      const uint4 a = lds_read4(i), b = lds_read4(i + C.cap_sph), c = lds_read4(i + 2 * C.cap_sph), d = lds_read4(i + 3 * C.cap_sph);
+      const V3 c0 = mk(u2d(a.x, a.y), u2d(a.z, a.w), u2d(b.x, b.y)), dc = mk(u2d(b.z, b.w), u2d(c.x, c.y), u2d(c.z, c.w));
+      const double radius = u2d(d.x, d.y);
+      hrec.pt = r.wo + (best_t * r.wd);
+      const V3 center = c0 + (r.time * dc);
+      const V3 outward = FAST ? (hrec.pt - center) * fast_rcp(radius) : (hrec.pt - center) / radius;
+      hrec.front = dot(r.wd, outward) < 0.0;
+      hrec.n = hrec.front ? outward : -outward;
+      hrec.mat = MATK_ID(r.best_mat);
+    }
+#define CHIP_FIRST_KIND(KIND)                                                                                          \
+  if (__any(kind == KIND)) {                                                                                           \
+    if (kind == KIND)                                                                                                  \
+      cont = shade_material<KIND, FAST, true, false, false>(S, B, 0u, pixel, stratum, S.materials[hrec.mat], hrec, r.wd, xw, klo, khi, no, nd); \
+  }
+    CHIP_FIRST_KIND(MK_LAMBERTIAN)
+    CHIP_FIRST_KIND(MK_METAL)
+    CHIP_FIRST_KIND(MK_DIELECTRIC)
+    CHIP_FIRST_KIND(MK_DIFFUSE_LIGHT)
+    CHIP_FIRST_KIND(MK_ISOTROPIC)
+#undef CHIP_FIRST_KIND
+    if (kind == MK_COUNT) {
+      xw[0] = (float)S.cam.background[0]; xw[1] = (float)S.cam.background[1]; xw[2] = (float)S.cam.background[2];
+    }
+    Affine f;
+    affine_identity(f);
+    if (has) {
+      if (cont) {
+        affine_compose(f, xw, klo, khi);
+        xw[0] = 0.f; xw[1] = 0.f; xw[2] = 0.f;
+        cont = !last_bounce;
+      }
+      if (!cont) finish_path(P, entry, f, xw);  // (at bounce 0 entry i is path i)
+    }
+    // 4. the paths that go on become entries of bounce 1
+    const unsigned long long mc = __ballot(cont);
+    if (mc) {
+      const uint32_t k = (uint32_t)__popcll(mc);
+      uint32_t base1 = o_next, n1 = k, base2 = 0;
+      if (out_range == 0u) {
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(&ctr_next[0], k);
+        base1 = __builtin_amdgcn_readfirstlane(g);
+      } else if (o_end - o_next >= k) {
+        o_next += k;
+      } else {
+        n1 = o_end - o_next;
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(&ctr_next[0], out_range);
+        base2 = __builtin_amdgcn_readfirstlane(g);
+        o_next = base2 + (k - n1);
+        o_end = base2 + out_range;
+      }
+      if (cont) {
+        const uint32_t rank = (uint32_t)__popcll(mc & lanes_below);
+        const uint32_t out = rank < n1 ? base1 + rank : base2 + (rank - n1);
+        uint4* pr = reinterpret_cast<uint4*>(ray_out + out);
+        uint4 q0, q1, q2, q3;
+        d2u(no.x, q0.x, q0.y); d2u(no.y, q0.z, q0.w);
+        d2u(no.z, q1.x, q1.y); d2u(nd.x, q1.z, q1.w);
+        d2u(nd.y, q2.x, q2.y); d2u(nd.z, q2.z, q2.w);
+        d2u(r.time, q3.x, q3.y); q3.z = entry; q3.w = 0u;
+        pr[0] = q0; pr[1] = q1; pr[2] = q2; pr[3] = q3;
+        uint4* pm = reinterpret_cast<uint4*>(st_out + out);
+        pm[0] = make_uint4(entry | f.clamped, __float_as_uint(f.b[0]), __float_as_uint(f.b[1]), __float_as_uint(f.b[2]));
+        pm[1] = make_uint4(__float_as_uint(f.bound[0]), __float_as_uint(f.bound[1]), __float_as_uint(f.bound[2]), 0u);
+      }
+    }
+  }
+  // what is left of the wave's last range holds no path
+  for (uint32_t i = o_next + lane; i < o_end; i += 64u) reinterpret_cast<uint4*>(ray_out + i)[3] = make_uint4(0u, 0u, CHIP_DEAD_ID, 0u);
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt.bvh += __shfl_down(cnt.bvh, off);
+    cnt.prim += __shfl_down(cnt.prim, off);
+    nseg += __shfl_down(nseg, off);
+  }
+  if (lane == 0 && nseg) {
+    atomicAdd(&P.stats[0], (unsigned long long)nseg);
+    atomicAdd(&P.stats[1], (unsigned long long)cnt.bvh);
+    atomicAdd(&P.stats[2], (unsigned long long)cnt.prim);
   }
 }
 

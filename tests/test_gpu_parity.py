@@ -844,6 +844,41 @@ def test_compact_sphere_form_equals_general_form(pkg, gpu, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_first_bounce_in_one_kernel_equals_two_kernel_form(pkg, gpu, oracle, monkeypatch):
+    """Small sphere scenes with solid colours trace and shade bounce 0 in one kernel (k_first_small: camera ray,
+    closest hit and material code per wave, bounce-1 entries handed out in ranges); CHIP_NO_FUSED_FIRST=1 selects the
+    traversal kernel followed by the bounce-0 shade kernel.  Both forms run the same arithmetic per path, so the images
+    are the same bits in both shading modes, also when a batch leaves empty entries in bounce 1 (a frame large enough for
+    ranged hand-out) and with four stack words per lane, when most camera rays go through the literal queue and are
+    shaded by the shade kernel's pass over that queue.  The one-kernel form is also compared with the oracle."""
+    monkeypatch.delenv("CHIP_NO_FUSED_FIRST", raising=False)
+    X = pkg.bindings.RENDER_EXACT_SHADING
+    for name, kw, seed in (("random_spheres", dict(width=160, spp=16, depth=12), 5), ("three_spheres", dict(width=120, spp=9, depth=1), 2),
+                           ("three_spheres", dict(width=120, spp=9, depth=2), 2), ("random_spheres", dict(width=1920, spp=4, depth=6), 3)):
+        sc = pkg.scenes.build(gpu, name, **kw)
+        for flags in (0, X):
+            one, _, st1 = sc.render_frame(seed=seed, flags=flags)
+            monkeypatch.setenv("CHIP_NO_FUSED_FIRST", "1")
+            two, _, st2 = sc.render_frame(seed=seed, flags=flags)
+            monkeypatch.delenv("CHIP_NO_FUSED_FIRST")
+            assert st1["segments"] == st2["segments"] and st1["paths"] == st2["paths"], (name, kw, flags)
+            assert np.array_equal(one.view(np.uint32), two.view(np.uint32)), (name, kw, flags)
+    sc = pkg.scenes.build(gpu, "random_spheres", width=160, spp=16, depth=12)
+    want, _, st0 = sc.render_frame(seed=5)
+    monkeypatch.setenv("CHIP_SMALL_STACK", "4")
+    tight, _, st1 = sc.render_frame(seed=5)
+    monkeypatch.delenv("CHIP_SMALL_STACK")
+    assert st0["segments"] == st1["segments"] and np.array_equal(want.view(np.uint32), tight.view(np.uint32))
+    so = pkg.scenes.build(oracle, "random_spheres", width=96, spp=4, depth=12)
+    sg = pkg.scenes.build(gpu, "random_spheres", width=96, spp=4, depth=12)
+    img_o, _, st_o = so.render_frame(seed=7, sum_dtype=np.float64)
+    img_g, _, st_g = sg.render_frame(seed=7, flags=X)
+    assert st_g["segments"] == st_o["segments"]
+    diff = np.abs(img_g.astype(np.float64) - img_o)
+    assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
+
+
+@pytest.mark.gpu
 def test_literal_hand_over_of_every_fifth_ray(pkg, gpu):
     """The ordered traversal hands a ray it cannot take (a zero direction component, a descent deeper than the compact
     form's stack) to the literal traversal, which runs as a pass of its own after it: a ray or two per frame in the
