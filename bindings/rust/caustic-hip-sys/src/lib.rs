@@ -48,6 +48,9 @@ pub const CHIP_RENDER_TIME_KERNELS: u32 = 1;
 pub const CHIP_RENDER_EXACT_SHADING: u32 = 2;
 pub const CHIP_RENDER_REFERENCE_ORDER: u32 = 4;
 pub const CHIP_RENDER_QUANTISE_255: u32 = 8;
+pub const CHIP_SCENE_EXACT_SHADING_FORCED: c_int = 1;
+pub const CHIP_SCENE_REFERENCE_ORDER_FORCED: c_int = 2;
+pub const CHIP_SCENE_FUSED_FIRST_BOUNCE: c_int = 4;
 
 /// `HitRecord` of `object/mod.rs:31-39`, filled by `chip_trace_rays`.
 #[repr(C)]
@@ -161,6 +164,8 @@ extern "C" {
     pub fn chip_commit(s: *mut chip_scene) -> c_int;
     pub fn chip_image_size(s: *mut chip_scene, width: *mut u32, height: *mut u32) -> c_int;
     pub fn chip_sqrt_spp(s: *mut chip_scene) -> c_int;
+    /// CHIP_SCENE_* bits of the committed scene: what takes it off the default render path (forced exact shading, forced reference order).
+    pub fn chip_scene_traits(s: *mut chip_scene) -> c_int;
     pub fn chip_camera_derived(s: *mut chip_scene, out24: *mut f64) -> c_int;
     pub fn chip_render_frame(s: *mut chip_scene, opts: *const chip_render_opts, out_sum_rgb: *mut f32, out_rgb8: *mut u8, stats: *mut chip_stats) -> c_int;
     pub fn chip_render_accumulate_device(s: *mut chip_scene, opts: *const chip_render_opts, d_sum_rgb: *mut f32, stream: *mut c_void, stats: *mut chip_stats) -> c_int;

@@ -191,6 +191,21 @@ int chip_scene_set_camera(chip_scene* s, const chip_camera_desc* desc); /* Camer
 int chip_commit(chip_scene* s);
 int chip_image_size(chip_scene* s, uint32_t* width, uint32_t* height); /* camera.rs:397-404 */
 int chip_sqrt_spp(chip_scene* s);                                       /* camera.rs:131 */
+/* How the committed scene will be rendered, as CHIP_SCENE_* bits (no counterpart in the reference, which has one way to
+ * render): some scene contents take the library off its default path, at a cost in speed that a caller may want to know
+ * about instead of finding it in the frame time.  < 0 when the scene is not committed. */
+enum {
+  /* Every render shades with the reference's f64 operation order, as if CHIP_RENDER_EXACT_SHADING were set: the scene
+   * holds a Disc whose normal is not of unit length (disc.rs:24-54 keeps the normal as given, and lambertian.rs then
+   * weighs a bounce by its length, which the fast arithmetic's unit-normal shortcuts do not reproduce). */
+  CHIP_SCENE_EXACT_SHADING_FORCED = 1,
+  /* Every ray is traced in the reference's own visiting order, as if CHIP_RENDER_REFERENCE_ORDER were set: the scene holds
+   * a primitive that reaches outside its own bounding box (a tilted Disc, disc.rs:25-35), which only that order finds. */
+  CHIP_SCENE_REFERENCE_ORDER_FORCED = 2,
+  /* Bounce 0 runs in one kernel (traversal and shading fused): small scenes of bare spheres with solid colours. */
+  CHIP_SCENE_FUSED_FIRST_BOUNCE = 4
+};
+int chip_scene_traits(chip_scene* s);
 /* The derived Camera fields of camera.rs:166-181 as 24 doubles: center, pixel00_loc, pixel_delta_u,
  * pixel_delta_v, defocus_disk_u, defocus_disk_v, then pixel_samples_scale, reciprocal_sqrt_spp,
  * defocus_angle, sqrt_spp, image_width, image_height. */

@@ -115,6 +115,9 @@ FLAT_NODE_DTYPE = np.dtype(
     [("kind", "<i4"), ("mat", "<i4"), ("first", "<i4"), ("count", "<i4"), ("flags", "<u4"), ("reserved", "<u4"), ("v", "<f8", (9,))]
 )
 assert FLAT_NODE_DTYPE.itemsize == 96
+SCENE_EXACT_SHADING_FORCED = 1
+SCENE_REFERENCE_ORDER_FORCED = 2
+SCENE_FUSED_FIRST_BOUNCE = 4
 FLAT_MOVING = 1
 FLAT_MEDIUM_TEX = 2
 
@@ -204,6 +207,7 @@ class Backend:
             "render_frame_multi": (i, [p, C.POINTER(RenderOpts), p, C.POINTER(C.c_uint8), C.POINTER(Stats)]),
             "render_accumulate_noalloc": (i, [p, C.POINTER(RenderOpts), p, p, C.POINTER(Stats)]),
             "noalloc_max_pixels": (C.c_uint32, []),
+            "scene_traits": (i, [p]),
         }.items():
             if hasattr(self.lib, self.prefix + name):
                 f = self.fn(name)
@@ -439,6 +443,10 @@ class Scene:
 
     def sqrt_spp(self):
         return self._call("sqrt_spp")
+
+    def traits(self):
+        """SCENE_* bits: what takes the committed scene off the library's default render path."""
+        return self._call("scene_traits")
 
     def camera_derived(self):
         out = np.zeros(24, dtype=np.float64)

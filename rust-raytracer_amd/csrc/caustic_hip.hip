@@ -162,6 +162,7 @@ struct DeviceState {
   DevBuf<DPerlin> d_perlins;
   DevBuf<uint8_t> d_texels;
   DevBuf<DLight> d_lights;
+  DevBuf<DLightNode> d_ltree;
   DScene dscene;
   PoolBufs pools[kMaxLanes];
   LaneRes lanes[kMaxLanes];
@@ -179,7 +180,7 @@ struct DeviceState {
   void release_tables() {
     d_bvh.release(); d_wnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release();
     d_translates.release(); d_rotates.release(); d_scales.release(); d_discs.release(); d_cones.release(); d_media.release(); d_xchain.release(); d_materials.release();
-    d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release();
+    d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release(); d_ltree.release();
     uploaded = false;
   }
   // (with this state's device current)
@@ -962,12 +963,14 @@ static int upload_scene(chip_scene* s, DeviceState& D, const Flat& F) {
   HIP_TRY(D.d_perlins.upload(s->host.perlins));
   HIP_TRY(D.d_texels.upload(s->host.texels));
   HIP_TRY(D.d_lights.upload(F.lights));
+  HIP_TRY(D.d_ltree.upload(F.ltree));
   DScene& T = D.dscene;
   T.bvh = D.d_bvh.p; T.wnodes = D.d_wnodes.p; T.spheres = D.d_spheres.p; T.quads = D.d_quads.p; T.groups = D.d_groups.p; T.gchild = D.d_gchild.p;
   T.translates = D.d_translates.p; T.rotates = D.d_rotates.p; T.scales = D.d_scales.p; T.discs = D.d_discs.p; T.cones = D.d_cones.p;
   T.media = D.d_media.p; T.xchain = D.d_xchain.p;
   T.materials = D.d_materials.p; T.textures = D.d_textures.p; T.perlins = D.d_perlins.p; T.texels = D.d_texels.p;
   T.lights = D.d_lights.p;
+  T.ltree = D.d_ltree.p;
   T.root = F.root;
   T.ord_root = F.ord_root;
   T.n_lights = (uint32_t)F.lights.size();
@@ -1436,6 +1439,19 @@ int chip_sqrt_spp(chip_scene* s) {
   NEED_SCENE;
   if (!s->host.has_camera) return fail("scene has no camera");
   return (int)s->host.cam.sqrt_spp;
+}
+int chip_scene_traits(chip_scene* s) {
+  NEED_SCENE;
+  if (!s->committed) return fail("scene not committed");
+  int bits = 0;
+  if (s->flat.nonunit_normals) bits |= CHIP_SCENE_EXACT_SHADING_FORCED;
+  if (s->flat.loose_geometry) bits |= CHIP_SCENE_REFERENCE_ORDER_FORCED;
+  const uint32_t feat = scene_features(s->flat);
+  bool solid_only = !s->flat.has_lights;
+  for (const DTexture& t : s->host.textures) solid_only = solid_only && t.kind == TK_SOLID;
+  const ExtendPlans X = plan_extends(s, feat);
+  if (feat == 0 && solid_only && X.feat == 0 && X.full.cache && X.full.small && !s->flat.loose_geometry) bits |= CHIP_SCENE_FUSED_FIRST_BOUNCE;
+  return bits;
 }
 int chip_camera_derived(chip_scene* s, double* out) {
   NEED_SCENE;

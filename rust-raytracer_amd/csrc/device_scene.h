@@ -178,6 +178,17 @@ enum : uint32_t { LK_SPHERE = 1, LK_QUAD = 2, LK_DISC = 3, LK_CONE_WALL = 4, LK_
 struct DLight {
   uint32_t kind;
   uint32_t index;  // into spheres / quads / discs / cones
+  // Share of this light in the light list's pdf (group.rs:60-69): 1 / len for a member of the lights Group, the product
+  // of the shares along the way for a member of a Group nested inside it.
+  double weight;
+};
+// The lights node as a tree, for drawing a sample the way group.rs:71-78 does (one uniform pick per Group on the way down):
+// node 0 is the lights Group itself; a group's children are nodes first .. first + count - 1; a leaf names its DLight.
+#define CHIP_LIGHT_DEPTH 16  // Groups nested inside the lights Group, at most
+struct DLightNode {
+  uint32_t is_group;
+  uint32_t first, count;
+  uint32_t leaf;
 };
 
 struct DCamera {  // Camera, camera.rs:202-231
@@ -206,6 +217,7 @@ struct DScene {
   const DPerlin* perlins;
   const uint8_t* texels;
   const DLight* lights;
+  const DLightNode* ltree;
   nref_t root;
   nref_t ord_root;  // the ordered traversal's starting node (differs from root when that is a Group)
   uint32_t n_lights;

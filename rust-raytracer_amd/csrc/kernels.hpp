@@ -1342,18 +1342,27 @@ __device__ inline V3 light_random_one(const DScene& S, const DLight& L, V3 origi
 template <bool EXT>
 __device__ inline double lights_pdf(const DScene& S, V3 origin, V3 dir) {
   if (!S.lights_is_group) return light_pdf_one<EXT>(S, S.lights[0], origin, dir);
-  double weight = 1.0 / (double)S.n_lights;
+  // group.rs:60-69 over the leaves of the lights Group, each with its share (1 / len for a direct member; members of a
+  // Group nested inside carry the product of the shares on the way, which regroups the reference's nested sums)
   double sum = 0.0;
-  for (uint32_t i = 0; i < S.n_lights; i++) sum += weight * light_pdf_one<EXT>(S, S.lights[i], origin, dir);
+  for (uint32_t i = 0; i < S.n_lights; i++) sum += S.lights[i].weight * light_pdf_one<EXT>(S, S.lights[i], origin, dir);
   return sum;
 }
 template <bool EXT>
 __device__ inline V3 lights_random(const DScene& S, V3 origin, Rng& rng) {
   if (!S.lights_is_group) return light_random_one<EXT>(S, S.lights[0], origin, rng);
-  if (S.n_lights == 0) return mk(0.0, 1.0, 0.0);
-  uint32_t i = (uint32_t)(long long)(rng.next() * (double)S.n_lights);  // rand_int_interval(0, len)
-  if (i >= S.n_lights) i = S.n_lights - 1;
-  return light_random_one<EXT>(S, S.lights[i], origin, rng);
+  // group.rs:71-78: one uniform pick per Group on the way down; an empty Group answers (0, 1, 0)
+  uint32_t node = 0;
+  for (int depth = 0; depth < CHIP_LIGHT_DEPTH; depth++) {
+    const DLightNode g = S.ltree[node];
+    if (g.count == 0) return mk(0.0, 1.0, 0.0);
+    uint32_t i = (uint32_t)(long long)(rng.next() * (double)g.count);  // rand_int_interval(0, len)
+    if (i >= g.count) i = g.count - 1;
+    const DLightNode c = S.ltree[g.first + i];
+    if (!c.is_group) return light_random_one<EXT>(S, S.lights[c.leaf], origin, rng);
+    node = g.first + i;
+  }
+  return mk(0.0, 1.0, 0.0);  // (not reached: the host refuses deeper nesting)
 }
 
 // ------------------------------------------------------------------ queue helpers (wave64 ballot + prefix popcount)

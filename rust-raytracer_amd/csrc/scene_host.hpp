@@ -101,6 +101,7 @@ struct Flat {
   std::vector<DMedium> media;
   std::vector<nref_t> xchain;
   std::vector<DLight> lights;
+  std::vector<DLightNode> ltree;
   nref_t root = NREF_NONE;
   uint32_t has_lights = 0, lights_is_group = 0;
   uint32_t loose_geometry = 0;  // some primitive of the world is not bounded by its own box
@@ -647,16 +648,36 @@ struct HostScene {
       throw std::runtime_error("unknown node kind");
     }
 
-    void emit_light(int h) {
+    // One member of the lights node: a leaf with its share of the pdf, or a Group (a ConeFrustum samples as its Group,
+    // cone.rs:91-97) whose members follow, each with 1 / len of the Group's share (group.rs:60-78).
+    void emit_light_leaf(int h, double weight) {
       const HNode& n = H.nodes[h];
       DLight L;
       if (n.kind == CHIP_NODE_SPHERE) { L.kind = LK_SPHERE; L.index = NREF_INDEX(emit_sphere(n, NREF_NONE, n.id)); }
       else if (n.kind == CHIP_NODE_QUAD) { L.kind = LK_QUAD; L.index = NREF_INDEX(emit_quad(n, NREF_NONE, n.id)); }
       else if (n.kind == CHIP_NODE_DISC) { L.kind = LK_DISC; L.index = NREF_INDEX(emit_disc(n, NREF_NONE, n.id)); }
       else if (n.kind == CHIP_NODE_CONE_WALL) { L.kind = LK_CONE_WALL; L.index = NREF_INDEX(emit_cone(n, NREF_NONE, n.id)); }
-      else if (n.kind == CHIP_NODE_GROUP || n.kind == CHIP_NODE_CONE) throw std::runtime_error("nested Group inside the lights group is not supported");
       else { L.kind = LK_OTHER; L.index = 0; }  // Node::pdf_value / random defaults (object/mod.rs:59-65)
+      L.weight = weight;
       F.lights.push_back(L);
+    }
+    // Fills tree node `at` (already in F.ltree) for the Group `h` whose share of the pdf is `share`.
+    void emit_light_group(int h, size_t at, double share, int depth) {
+      if (depth >= CHIP_LIGHT_DEPTH) throw std::runtime_error("Groups inside the lights Group are nested deeper than 16 levels");
+      const std::vector<int> kids = H.nodes[h].kids;
+      const size_t first = F.ltree.size();
+      F.ltree[at] = DLightNode{1u, (uint32_t)first, (uint32_t)kids.size(), 0u};
+      F.ltree.resize(first + kids.size(), DLightNode{0u, 0u, 0u, 0u});
+      const double weight = share * (1.0 / (double)kids.size());
+      for (size_t k = 0; k < kids.size(); k++) {
+        const HNode& c = H.nodes[kids[k]];
+        if (c.kind == CHIP_NODE_GROUP || c.kind == CHIP_NODE_CONE) {
+          emit_light_group(kids[k], first + k, weight, depth + 1);
+        } else {
+          F.ltree[first + k] = DLightNode{0u, 0u, 0u, (uint32_t)F.lights.size()};
+          emit_light_leaf(kids[k], weight);
+        }
+      }
     }
   };
 
@@ -671,10 +692,11 @@ struct HostScene {
       const HNode& L = nodes[handle[lights]];
       if (L.kind == CHIP_NODE_GROUP || L.kind == CHIP_NODE_CONE) {  // a ConeFrustum samples as its Group (cone.rs:91-97)
         F.lights_is_group = 1;
-        for (int k : L.kids) fl.emit_light(k);
+        F.ltree.assign(1, DLightNode{1u, 0u, 0u, 0u});
+        fl.emit_light_group(handle[lights], 0, 1.0, 0);
       } else {
         F.lights_is_group = 0;
-        fl.emit_light(handle[lights]);
+        fl.emit_light_leaf(handle[lights], 1.0);
       }
     }
     reorder_bvh_breadth_first(F);

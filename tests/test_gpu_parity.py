@@ -458,11 +458,13 @@ def test_next_week_rank_share_of_full_configuration_against_oracle(pkg, gpu, ora
         assert p99 <= 2e-5 and worst <= 1e-3 and mean <= 5e-6, (rect, med, p99, worst, mean)
 
 
-@pytest.mark.parametrize("variant", ["bare_quad", "bare_sphere", "empty_group", "group_with_unsampled_members", "disc", "frustum"])
+@pytest.mark.parametrize("variant", ["bare_quad", "bare_sphere", "empty_group", "group_with_unsampled_members", "disc", "frustum", "nested_groups",
+                                     "nested_empty_and_frustum"])
 def test_light_list_shapes(pkg, gpu, oracle, variant):
     """SceneData.lights in every shape camera.rs:278-305 can meet: a node that is not a Group (its own pdf_value /
     random), an empty Group (group.rs:60-78: pdf 0, direction (0,1,0)), a Group with members that keep the Node
-    defaults (object/mod.rs:59-65: pdf 0, direction (1,0,0)), a Disc, a ConeFrustum.  Same-seed render against the
+    defaults (object/mod.rs:59-65: pdf 0, direction (1,0,0)), a Disc, a ConeFrustum, Groups inside the Group (each level
+    takes 1 / len of its parent's share of the pdf and one uniform pick of a sample).  Same-seed render against the
     oracle with the reference's f64 operation order."""
     def build(be):
         sc = be.new_scene()
@@ -486,6 +488,8 @@ def test_light_list_shapes(pkg, gpu, oracle, variant):
             "group_with_unsampled_members": lambda: sc.group([lq, box, ts]),
             "disc": lambda: sc.group([ld, lq]),
             "frustum": lambda: cone,
+            "nested_groups": lambda: sc.group([lq, sc.group([ld, sc.group([gs, lq])]), ts]),
+            "nested_empty_and_frustum": lambda: sc.group([sc.group([]), sc.group([cone, ld]), lq]),
         }[variant]()
         sc.set_lights(lights)
         sc.set_camera(image_width=64, aspect_ratio=1.5, samples_per_pixel=36, max_depth=8, vertical_fov=45, look_from=(0.0, 3.0, 9.0),

@@ -349,6 +349,17 @@ def test_disc_with_a_normal_of_any_length_renders_like_the_oracle(pkg, gpu, orac
         sc.commit()
         return sc
     sg, so = build(gpu), build(oracle)
+    # the library says what the scene's contents cost it (chip_scene_traits): a normal of another length than 1 forces the
+    # reference's shading arithmetic, a tilted disc (which reaches outside its own box, disc.rs:25-35) the reference's order
+    B = pkg.bindings
+    unit = abs(sum(c * c for c in normal) - 1.0) < 1e-12
+    tilted = normal == (0.3, 0.2, 1.0)  # (its z component exceeds 0.9, so its box is the flat one of an axis-aligned disc)
+    t = sg.traits()
+    assert bool(t & B.SCENE_EXACT_SHADING_FORCED) == (not unit)
+    assert bool(t & B.SCENE_REFERENCE_ORDER_FORCED) == tilted
+    assert not t & B.SCENE_FUSED_FIRST_BOUNCE
+    assert pkg.scenes.build(gpu, "random_spheres", width=32, spp=1, depth=2).traits() == B.SCENE_FUSED_FIRST_BOUNCE
+    assert pkg.scenes.build(gpu, "cornell_box", width=32, spp=1, depth=2).traits() == 0
     w, _, sw = so.render_frame(seed=9, sum_dtype=np.float64)
     for flags in (pkg.bindings.RENDER_EXACT_SHADING, 0):
         f, _, sf = sg.render_frame(seed=9, flags=flags)
