@@ -235,9 +235,13 @@ static uint32_t scene_features(const Flat& F) {
   const uint32_t ext = (!F.discs.empty() || !F.cones.empty() || !F.scales.empty()) ? (TF_QUADS | TF_XFORM | TF_EXT) : 0u;
   if (!F.media.empty()) {
     uint32_t f = TF_QUADS | TF_XFORM | TF_MEDIA | ext;
-    for (const DMedium& m : F.media)
-      if (NREF_KIND(m.boundary) != NK_SPHERE) f |= TF_MEDIA_ANY;
+    // boundaries: bare spheres and boxes are queried in place; anything else needs the variant with the sub-traversal
+    for (const DMedium& m : F.media) {
+      if (m.bq_count != 0) f |= TF_MEDIA_BOX;
+      else if (NREF_KIND(m.boundary) != NK_SPHERE) f |= TF_MEDIA_ANY;
+    }
     if (ext) f |= TF_MEDIA_ANY;  // media together with discs / cones / Scale: only the variant with everything exists
+    if (f & TF_MEDIA_ANY) f &= ~(uint32_t)TF_MEDIA_BOX;  // (that variant queries boxes in place as well)
     return f;
   }
   if (ext) return ext;
@@ -542,6 +546,7 @@ static uint32_t extend_variant(uint32_t feat) {
     case TF_QUADS | TF_XFORM | TF_NO_QUADROT:
     case TF_QUADS | TF_XFORM | TF_EXT:
     case TF_QUADS | TF_XFORM | TF_MEDIA:
+    case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_BOX:
     case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: return feat;
     default: return TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT | TF_MEDIA_ANY;
   }
@@ -596,6 +601,7 @@ static int launch_extend(const DeviceState& D, const PathPool& P, const ExtendPl
     case TF_QUADS | TF_XFORM | TF_NO_QUADROT: CHIP_EXT(TF_QUADS | TF_XFORM | TF_NO_QUADROT)
     case TF_QUADS | TF_XFORM | TF_EXT: CHIP_EXT(TF_QUADS | TF_XFORM | TF_EXT)
     case TF_QUADS | TF_XFORM | TF_MEDIA: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA)
+    case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_BOX: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_BOX)
     case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY)
     default: CHIP_EXT(TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT | TF_MEDIA_ANY)
   }
@@ -1808,6 +1814,7 @@ int chip_trace_rays(chip_scene* s, uint64_t seed, size_t n, const double* o, con
       case TF_QUADS | TF_XFORM: CHIP_TRACE(TF_QUADS | TF_XFORM); break;
       case TF_QUADS | TF_XFORM | TF_NO_QUADROT: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_NO_QUADROT); break;
       case TF_QUADS | TF_XFORM | TF_MEDIA: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA); break;
+      case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_BOX: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_BOX); break;
       case TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_ANY); break;
       case TF_QUADS | TF_XFORM | TF_EXT: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_EXT); break;
       default: CHIP_TRACE(TF_QUADS | TF_XFORM | TF_MEDIA | TF_EXT | TF_MEDIA_ANY); break;

@@ -146,6 +146,12 @@ struct alignas(8) DMedium {
   // (a medium node instanced in several places of the scene graph gives one record per place) owns its own keys, so
   // the media a ray meets draw independently, as they do from the reference's stream (constant_medium.rs:64).
   uint32_t sample_base;
+  // A boundary that is a Group of up to six quads (a box, box_node.rs:15-74), bare or inside a run of nested instances
+  // (translate / rotate / scale around nothing else), is queried in place: bq_count quads listed in gchild[bq_first ..],
+  // in the space of transform bx_inner (NREF_NONE: the medium's own space).  bq_count == 0: any other boundary.
+  nref_t bx_inner;
+  uint32_t bq_first, bq_count;
+  uint32_t pad;
 };
 
 enum : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_DIFFUSE_LIGHT = 3, MK_ISOTROPIC = 4, MK_EMPTY = 5, MK_COUNT = 6 };

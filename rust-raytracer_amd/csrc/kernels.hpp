@@ -566,14 +566,18 @@ __device__ inline bool sphere_hit(const SphereT& s, const TravRay& r, double tmi
   return true;
 }
 // quad.rs:144-169: t inside [tmin, tmax] inclusive, plane coordinates inside [0,1] inclusive
+__device__ inline bool quad_hit_od(const DQuad& q, V3 ro, V3 rd, double tmin, double tmax, double& t_out, double& alpha, double& beta);
 __device__ inline bool quad_hit(const DQuad& q, const TravRay& r, double tmin, double tmax, double& t_out, double& alpha, double& beta) {
+  return quad_hit_od(q, r.o, r.d, tmin, tmax, t_out, alpha, beta);
+}
+__device__ inline bool quad_hit_od(const DQuad& q, V3 ro, V3 rd, double tmin, double tmax, double& t_out, double& alpha, double& beta) {
   // quad.rs:128-157 without its early returns: every operand is asked for at once (one memory round trip instead of
   // two) and the conditions are combined at the end; the arithmetic that decides is the same, a rejected test merely
   // computes plane coordinates nobody looks at (comparisons with the NaN or infinity of a zero denominator are false)
   const V3 n = ld3(q.n), qq = ld3(q.q), w = ld3(q.w), v = ld3(q.v), u = ld3(q.u);
-  const double denom = dot(n, r.d);
-  const double t = (q.d - dot(n, r.o)) / denom;
-  const V3 p = r.o + (t * r.d);
+  const double denom = dot(n, rd);
+  const double t = (q.d - dot(n, ro)) / denom;
+  const V3 p = ro + (t * rd);
   const V3 planar = p - qq;
   alpha = dot(w, cross(planar, v));
   beta = dot(w, cross(u, planar));
@@ -676,11 +680,12 @@ __device__ inline bool ray_set_inv(TravRay& r) {
 }
 // Scene features a traversal / shade instantiation handles (scenes lacking a feature run a leaner variant):
 // quads & groups | Translate & Rotate | ConstantMedium | discs, cone walls & Scale
-// TF_MEDIA_ANY: some medium's boundary is more than a bare sphere (it needs the out-of-line sub-traversal, which
+// TF_MEDIA_ANY: some medium's boundary is more than a bare sphere (a box is queried in place, anything else by the out-of-line sub-traversal, which
 // costs the whole kernel registers; media bounded by spheres alone run without it)
 // TF_NO_QUADROT (with TF_QUADS | TF_XFORM only): groups and Translates but neither quads nor Rotates, the shape of
 // instanced-sphere scenes (what the OpenSCAD front end emits for spheres: Translate(Group[Sphere]))
-enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4, TF_EXT = 8, TF_MEDIA_ANY = 16, TF_NO_QUADROT = 32 };
+// TF_MEDIA_BOX: some medium is bounded by a box (queried in place, six quad tests), none by anything but a sphere or a box
+enum : uint32_t { TF_QUADS = 1, TF_XFORM = 2, TF_MEDIA = 4, TF_EXT = 8, TF_MEDIA_ANY = 16, TF_NO_QUADROT = 32, TF_MEDIA_BOX = 64 };
 
 // translate.rs:28 / rotate.rs:137-138 / scale.rs:97-98
 template <bool EXT>
@@ -995,7 +1000,34 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       if (ORD) r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);  // the boundary queries run the literal form
       double t1 = INFINITY, t2 = INFINITY;
       nref_t b1 = NREF_NONE, b2 = NREF_NONE;
-      if (!(F & TF_MEDIA_ANY) || NREF_KIND(m.boundary) == NK_SPHERE) {
+      if ((F & (TF_MEDIA_ANY | TF_MEDIA_BOX)) && m.bq_count != 0u) {
+        // A box (a Group of quads, bare or under instances that hold nothing else): both queries of constant_medium.rs:42-45
+        // from one pass over the quads.  A quad's plane distance does not depend on the interval it is asked over
+        // (quad.rs:144-157), and the Group keeps the smallest distance inside the interval (group.rs:44-54), so the
+        // first query's answer is the smallest distance of all and the second's the smallest one from t1 + 0.0001 on.
+        V3 bo = r.o, bd = r.d;
+        if ((F & TF_XFORM) && m.bx_inner != NREF_NONE) ray_to_space<(F & TF_EXT) != 0>(S, m.bx_inner, r.wo, r.wd, bo, bd);
+        double tq[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          tq[i] = NAN;
+          if ((uint32_t)i < m.bq_count) {
+            double t, al, be;
+            cnt.prim++;
+            if (quad_hit_od(S.quads[NREF_INDEX(S.gchild[m.bq_first + i])], bo, bd, -INFINITY, INFINITY, t, al, be)) tq[i] = t;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+          if (tq[i] < t1) { t1 = tq[i]; b1 = m.boundary; }  // (an entry without a hit is NaN and compares false; a hit's distance is finite)
+        if (b1 != NREF_NONE) {
+          const double lo2 = t1 + 0.0001;
+          cnt.prim += m.bq_count;  // (the reference tests the quads again)
+#pragma unroll
+          for (int i = 0; i < 6; i++)
+            if (tq[i] >= lo2 && (b2 == NREF_NONE || tq[i] < t2)) { t2 = tq[i]; b2 = m.boundary; }
+        }
+      } else if (!(F & TF_MEDIA_ANY) || NREF_KIND(m.boundary) == NK_SPHERE) {
         // the common boundary, a bare sphere: its two queries (constant_medium.rs:42-45) without the general traversal
         const DSphere& bs = S.spheres[NREF_INDEX(m.boundary)];
         double t;

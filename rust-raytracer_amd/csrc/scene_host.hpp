@@ -642,6 +642,26 @@ struct HostScene {
           m.leaf_id = n.id;
           m.tests = tests;
           m.sample_base = sample_base;
+          // the common boundary besides a sphere: a box, possibly inside instances that hold nothing else
+          m.bx_inner = NREF_NONE;
+          m.bq_first = m.bq_count = 0;
+          m.pad = 0;
+          {
+            nref_t inner = NREF_NONE, c = b;
+            for (int guard = 0; guard < 64; guard++) {
+              const uint32_t k = NREF_KIND(c), i = NREF_INDEX(c);
+              if (k == NK_TRANSLATE && F.translates[i].only_sphere == NREF_NONE) { inner = c; c = F.translates[i].child; }
+              else if (k == NK_ROTATE) { inner = c; c = F.rotates[i].child; }
+              else if (k == NK_SCALE) { inner = c; c = F.scales[i].child; }
+              else break;
+            }
+            if (NREF_KIND(c) == NK_GROUP) {
+              const DGroup g = F.groups[NREF_INDEX(c)];
+              bool quads_only = g.count >= 1 && g.count <= 6;
+              for (uint32_t j = 0; j < g.count && quads_only; j++) quads_only = NREF_KIND(F.gchild[g.first + j]) == NK_QUAD;
+              if (quads_only) { m.bx_inner = inner; m.bq_first = g.first; m.bq_count = g.count; }
+            }
+          }
           return NREF(NK_MEDIUM, idx);
         }
       }
