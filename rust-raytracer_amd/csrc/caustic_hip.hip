@@ -565,6 +565,13 @@ static ExtendPlans plan_extends(const chip_scene* s, uint32_t scene_feat) {
   X.small_queue = env.small_queue;
   return X;
 }
+// Whether bounce 0 runs in one kernel (k_first_small): small scenes of bare spheres (the compact form of the traversal)
+// with lean shading (solid colours, no lights).  CHIP_NO_FUSED_FIRST=1 selects the two-kernel form (read per call: tests
+// compare the two).
+static bool fused_first_possible(const ExtendPlans& X, bool lean) {
+  const char* e = getenv("CHIP_NO_FUSED_FIRST");
+  return lean && X.feat == 0 && X.full.cache && X.full.small && !(e && *e == '1');
+}
 // One bounce of traversal: the ordered traversal followed by a literal pass over the rays it handed back (normally none; all of
 // them in a reference_order render).
 // lit_expected: whether the literal queue is expected to hold rays (it sizes the literal pass's grid only: one block
@@ -629,7 +636,6 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   const bool exact_shading = (o->flags & CHIP_RENDER_EXACT_SHADING) != 0 || s->flat.nonunit_normals != 0;
   const uint32_t feat = scene_features(s->flat);
   const ExtendPlans xplans = plan_extends(s, feat);
-  const bool no_fused_first = [] { const char* e = getenv("CHIP_NO_FUSED_FIRST"); return e && *e == '1'; }();  // (per call: tests compare both forms)
   // spheres with solid colours and no light sampling: the lean shade kernels
   bool solid_only = !s->flat.has_lights;
   for (const DTexture& t : s->host.textures) solid_only = solid_only && t.kind == TK_SOLID;
@@ -638,7 +644,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   // solid colours and checkers only: the full shade kernel without its image / noise texture code
   bool plain_textures = true;
   for (const DTexture& t : s->host.textures) plain_textures = plain_textures && (t.kind == TK_SOLID || t.kind == TK_CHECKER);
-  const bool fused_first_ok = lean && xplans.feat == 0 && xplans.full.cache && xplans.full.small && !no_fused_first;
+  const bool fused_first_ok = fused_first_possible(xplans, lean);
   const bool lean_xform = solid_only && (feat & ~TF_NO_QUADROT) == (TF_QUADS | TF_XFORM) && s->flat.quads.empty() && s->flat.media.empty();
 
   // pools: two when the render is large enough to be worth splitting
@@ -1456,7 +1462,7 @@ int chip_scene_traits(chip_scene* s) {
   bool solid_only = !s->flat.has_lights;
   for (const DTexture& t : s->host.textures) solid_only = solid_only && t.kind == TK_SOLID;
   const ExtendPlans X = plan_extends(s, feat);
-  if (feat == 0 && solid_only && X.feat == 0 && X.full.cache && X.full.small && !s->flat.loose_geometry) bits |= CHIP_SCENE_FUSED_FIRST_BOUNCE;
+  if (fused_first_possible(X, feat == 0 && solid_only) && !s->flat.loose_geometry) bits |= CHIP_SCENE_FUSED_FIRST_BOUNCE;
   return bits;
 }
 int chip_camera_derived(chip_scene* s, double* out) {

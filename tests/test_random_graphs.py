@@ -358,7 +358,9 @@ def test_disc_with_a_normal_of_any_length_renders_like_the_oracle(pkg, gpu, orac
     assert bool(t & B.SCENE_EXACT_SHADING_FORCED) == (not unit)
     assert bool(t & B.SCENE_REFERENCE_ORDER_FORCED) == tilted
     assert not t & B.SCENE_FUSED_FIRST_BOUNCE
-    assert pkg.scenes.build(gpu, "random_spheres", width=32, spp=1, depth=2).traits() == B.SCENE_FUSED_FIRST_BOUNCE
+    import os
+    tuned = any(os.environ.get(k) == "1" for k in ("CHIP_NO_FUSED_FIRST", "CHIP_NO_LDS_CACHE", "CHIP_NO_SMALL_FORM"))  # (sweeps under other settings)
+    assert pkg.scenes.build(gpu, "random_spheres", width=32, spp=1, depth=2).traits() == (0 if tuned else B.SCENE_FUSED_FIRST_BOUNCE)
     assert pkg.scenes.build(gpu, "cornell_box", width=32, spp=1, depth=2).traits() == 0
     w, _, sw = so.render_frame(seed=9, sum_dtype=np.float64)
     for flags in (pkg.bindings.RENDER_EXACT_SHADING, 0):
