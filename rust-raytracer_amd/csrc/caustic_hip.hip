@@ -707,6 +707,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
       B.seed_lo = (uint32_t)o->seed;
       B.seed_hi = (uint32_t)(o->seed >> 32);
       B.reference_order = ((o->flags & CHIP_RENDER_REFERENCE_ORDER) || S.literal_only) ? 1u : 0u;
+      B.ray48 = exact_shading ? 0u : 1u;  // (the kernels of the default shading mode read and write the 48-byte ray record)
       bt.by = by;
       batches.push_back(bt);
     }

@@ -74,6 +74,12 @@ struct alignas(64) PathRay {  // what traversal reads and shading writes
   uint32_t id;   // path index in the batch, CHIP_DEAD_ID for a reserved entry that stayed empty
   uint32_t pad;
 };
+// In the default shading mode a ray record is 48 bytes: origin (3 x f64), direction as three floats, path id, time (f64),
+// one after the other at a 48-byte stride in the same array.  Scattered directions of that mode come from f32
+// trigonometry and f32-seeded reciprocals in the first place; rounding them to f32 where they are stored (once, in the
+// kernel that makes them: the traversal and the shading of the next bounce both read the rounded value back) takes a
+// quarter of the bytes a continuing path moves per bounce.  With CHIP_RENDER_EXACT_SHADING the record is PathRay.
+#define CHIP_RAY48_BYTES 48
 #define CHIP_DEAD_ID 0xFFFFFFFFu
 #define NREF_DEAD NREF(NK_NONE, 0x0FFFFFFE)  // PathHit.node of an empty entry
 struct alignas(16) PathHit {  // what traversal writes: closest hit of the current segment
@@ -121,6 +127,7 @@ struct BatchDesc {
   uint32_t tiles_per_row, tiles_magic[2];
   uint32_t seed_lo, seed_hi;
   uint32_t reference_order;                   // trace every ray in the reference's own visiting order
+  uint32_t ray48;                             // ray records are the 48-byte form (the default shading mode)
 };
 
 // ------------------------------------------------------------------ Philox4x32-10 stream
@@ -1444,14 +1451,29 @@ __device__ inline void finish_path(const PathPool& P, uint32_t slot, const Affin
   else atomicOr(&P.errflag[1], 1u);
 }
 // 16-byte accesses of a ray record
-__device__ inline void ray_load(const PathRay* rec, V3& o, V3& d, double& time, uint32_t& id) {
-  const double2* p = reinterpret_cast<const double2*>(rec);
-  double2 a = p[0], b = p[1], c = p[2];
-  const uint4 e = reinterpret_cast<const uint4*>(rec)[3];
-  o = mk(a.x, a.y, b.x);
-  d = mk(b.y, c.x, c.y);
-  time = u2d(e.x, e.y);
-  id = e.z;
+__device__ inline void ray_load(const PathRay* base, uint32_t entry, bool r48, V3& o, V3& d, double& time, uint32_t& id) {
+  if (r48) {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(base) + (size_t)entry * CHIP_RAY48_BYTES);
+    const uint4 a = p[0], b = p[1], c = p[2];
+    o = mk(u2d(a.x, a.y), u2d(a.z, a.w), u2d(b.x, b.y));
+    d = mk((double)__uint_as_float(b.z), (double)__uint_as_float(b.w), (double)__uint_as_float(c.x));
+    id = c.y;
+    time = u2d(c.z, c.w);
+  } else {
+    const PathRay* rec = base + entry;
+    const double2* p = reinterpret_cast<const double2*>(rec);
+    double2 a = p[0], b = p[1], c = p[2];
+    const uint4 e = reinterpret_cast<const uint4*>(rec)[3];
+    o = mk(a.x, a.y, b.x);
+    d = mk(b.y, c.x, c.y);
+    time = u2d(e.x, e.y);
+    id = e.z;
+  }
+}
+// Marks entry `entry` of a ray array empty (an entry reserved for a path that then ended).
+__device__ inline void ray_mark_dead(PathRay* base, uint32_t entry, bool r48) {
+  if (r48) reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(base) + (size_t)entry * CHIP_RAY48_BYTES)[2] = make_uint4(0u, CHIP_DEAD_ID, 0u, 0u);
+  else reinterpret_cast<uint4*>(base + entry)[3] = make_uint4(0u, 0u, CHIP_DEAD_ID, 0u);
 }
 
 // ---- quad-cooperative record access
@@ -1633,6 +1655,20 @@ __device__ inline void ray_pack(QuadRecord& q, V3 o, V3 d, double time, uint32_t
   d2u(o.z, q.w[1][0], q.w[1][1]); d2u(d.x, q.w[1][2], q.w[1][3]);
   d2u(d.y, q.w[2][0], q.w[2][1]); d2u(d.z, q.w[2][2], q.w[2][3]);
   d2u(time, q.w[3][0], q.w[3][1]); q.w[3][2] = id; q.w[3][3] = 0;
+}
+// the 48-byte form: [o.x o.y] [o.z | d.x d.y as floats] [d.z as float, id | time]
+__device__ inline void ray_unpack48(const QuadRecord& q, V3& o, V3& d, double& time, uint32_t& id) {
+  o = mk(u2d(q.w[0][0], q.w[0][1]), u2d(q.w[0][2], q.w[0][3]), u2d(q.w[1][0], q.w[1][1]));
+  d = mk((double)__uint_as_float(q.w[1][2]), (double)__uint_as_float(q.w[1][3]), (double)__uint_as_float(q.w[2][0]));
+  id = q.w[2][1];
+  time = u2d(q.w[2][2], q.w[2][3]);
+}
+__device__ inline void ray_pack48(QuadRecord& q, V3 o, V3 d, double time, uint32_t id) {
+  d2u(o.x, q.w[0][0], q.w[0][1]); d2u(o.y, q.w[0][2], q.w[0][3]);
+  d2u(o.z, q.w[1][0], q.w[1][1]);
+  q.w[1][2] = __float_as_uint((float)d.x); q.w[1][3] = __float_as_uint((float)d.y);
+  q.w[2][0] = __float_as_uint((float)d.z); q.w[2][1] = id;
+  d2u(time, q.w[2][2], q.w[2][3]);
 }
 __device__ inline void affine_unpack(const QuadRecord& q, Affine& f, uint32_t& id) {
   id = q.w[0][0] & ~CHIP_MAP_CLAMPED; f.clamped = q.w[0][0] & CHIP_MAP_CLAMPED;
@@ -1865,7 +1901,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
           uint32_t id = entry;  // at bounce 0 entry i is path i
           uint32_t tries = 0;
           if (B0) path_camera_ray(S, B, entry, r.wo, r.wd, r.time, tries);
-          else ray_load(ray_in + entry, r.wo, r.wd, r.time, id);
+          else ray_load(ray_in, entry, B.ray48 != 0u, r.wo, r.wd, r.time, id);
           const bool dead = !B0 && id == CHIP_DEAD_ID;  // reserved by the last shading pass but left empty
           if (dead) *reinterpret_cast<uint4*>(P.hit + entry) = make_uint4(0u, 0u, NREF_DEAD, 0u);
           // the culling form is computed first: it also tells whether the ordered traversal can take the ray
@@ -2123,7 +2159,7 @@ __global__ void __launch_bounds__(extend_block(0, true), extend_min_waves(0, tru
           uint32_t id = entry;
           uint32_t tries = 0;
           if (B0) path_camera_ray(S, B, entry, r.wo, r.wd, r.time, tries);
-          else ray_load(ray_in + entry, r.wo, r.wd, r.time, id);
+          else ray_load(ray_in, entry, B.ray48 != 0u, r.wo, r.wd, r.time, id);
           const bool dead = !B0 && id == CHIP_DEAD_ID;
           if (dead) *reinterpret_cast<uint4*>(P.hit + entry) = make_uint4(0u, 0u, NREF_DEAD, 0u);
           r.o = r.wo; r.d = r.wd;
@@ -2410,8 +2446,13 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
         if (valid) path_camera_ray(S, B, entry, ro, rd, rtime, tries);                                           \
       } else {                                                                                                   \
         QuadRecord q;                                                                                            \
-        quad_load<(int)sizeof(PathRay), 4>(ray_in, entry, lane, stage, q);                                            \
-        ray_unpack(q, ro, rd, rtime, id);                                                                        \
+        if constexpr (FAST) {                                                                                    \
+          quad_load<CHIP_RAY48_BYTES, 3>(ray_in, entry, lane, stage, q);                                         \
+          ray_unpack48(q, ro, rd, rtime, id);                                                                    \
+        } else {                                                                                                 \
+          quad_load<(int)sizeof(PathRay), 4>(ray_in, entry, lane, stage, q);                                     \
+          ray_unpack(q, ro, rd, rtime, id);                                                                      \
+        }                                                                                                        \
       }                                                                                                          \
       float xw[3] = {0.f, 0.f, 0.f}, klo = 0.f, khi = 0.f;                                                       \
       bool cont = false;                                                                                         \
@@ -2442,8 +2483,13 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
       const uint32_t out = cont ? s_base + out_rank : CHIP_NO_SLOT;                                              \
       {                                                                                                          \
         QuadRecord q;                                                                                            \
-        ray_pack(q, no, nd, rtime, id);                                                                          \
-        quad_store<(int)sizeof(PathRay), 4>(ray_out, out, lane, stage, q);                                            \
+        if constexpr (FAST) {                                                                                    \
+          ray_pack48(q, no, nd, rtime, id);                                                                      \
+          quad_store<CHIP_RAY48_BYTES, 3>(ray_out, out, lane, stage, q);                                         \
+        } else {                                                                                                 \
+          ray_pack(q, no, nd, rtime, id);                                                                        \
+          quad_store<(int)sizeof(PathRay), 4>(ray_out, out, lane, stage, q);                                     \
+        }                                                                                                        \
         affine_pack(q, f, id);                                                                                   \
         quad_store32(st_out, out, lane, stage, q);                                        \
       }                                                                                                          \
@@ -2473,7 +2519,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
     __syncthreads();
     // reserved entries that no path took
     for (uint32_t k = s_live + threadIdx.x; k < s_reserved; k += CHIP_BLOCK)
-      reinterpret_cast<uint4*>(ray_out + s_base + k)[3] = make_uint4(0u, 0u, CHIP_DEAD_ID, 0u);
+      ray_mark_dead(ray_out, s_base + k, FAST);
     __syncthreads();
   }
 }
@@ -2667,13 +2713,22 @@ __global__ void __launch_bounds__(extend_block(0, true), 4) k_first_small(DScene
       if (cont) {
         const uint32_t rank = (uint32_t)__popcll(mc & lanes_below);
         const uint32_t out = rank < n1 ? base1 + rank : base2 + (rank - n1);
-        uint4* pr = reinterpret_cast<uint4*>(ray_out + out);
-        uint4 q0, q1, q2, q3;
-        d2u(no.x, q0.x, q0.y); d2u(no.y, q0.z, q0.w);
-        d2u(no.z, q1.x, q1.y); d2u(nd.x, q1.z, q1.w);
-        d2u(nd.y, q2.x, q2.y); d2u(nd.z, q2.z, q2.w);
-        d2u(r.time, q3.x, q3.y); q3.z = entry; q3.w = 0u;
-        pr[0] = q0; pr[1] = q1; pr[2] = q2; pr[3] = q3;
+        if constexpr (FAST) {
+          uint4* pr = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(ray_out) + (size_t)out * CHIP_RAY48_BYTES);
+          uint4 q0, q1, q2;
+          d2u(no.x, q0.x, q0.y); d2u(no.y, q0.z, q0.w);
+          d2u(no.z, q1.x, q1.y); q1.z = __float_as_uint((float)nd.x); q1.w = __float_as_uint((float)nd.y);
+          q2.x = __float_as_uint((float)nd.z); q2.y = entry; d2u(r.time, q2.z, q2.w);
+          pr[0] = q0; pr[1] = q1; pr[2] = q2;
+        } else {
+          uint4* pr = reinterpret_cast<uint4*>(ray_out + out);
+          uint4 q0, q1, q2, q3;
+          d2u(no.x, q0.x, q0.y); d2u(no.y, q0.z, q0.w);
+          d2u(no.z, q1.x, q1.y); d2u(nd.x, q1.z, q1.w);
+          d2u(nd.y, q2.x, q2.y); d2u(nd.z, q2.z, q2.w);
+          d2u(r.time, q3.x, q3.y); q3.z = entry; q3.w = 0u;
+          pr[0] = q0; pr[1] = q1; pr[2] = q2; pr[3] = q3;
+        }
         uint4* pm = reinterpret_cast<uint4*>(st_out + out);
         pm[0] = make_uint4(entry | f.clamped, __float_as_uint(f.b[0]), __float_as_uint(f.b[1]), __float_as_uint(f.b[2]));
         pm[1] = make_uint4(__float_as_uint(f.bound[0]), __float_as_uint(f.bound[1]), __float_as_uint(f.bound[2]), 0u);
@@ -2681,7 +2736,7 @@ __global__ void __launch_bounds__(extend_block(0, true), 4) k_first_small(DScene
     }
   }
   // what is left of the wave's last range holds no path
-  for (uint32_t i = o_next + lane; i < o_end; i += 64u) reinterpret_cast<uint4*>(ray_out + i)[3] = make_uint4(0u, 0u, CHIP_DEAD_ID, 0u);
+  for (uint32_t i = o_next + lane; i < o_end; i += 64u) ray_mark_dead(ray_out, i, FAST);
   for (int off = 32; off > 0; off >>= 1) {
     cnt.bvh += __shfl_down(cnt.bvh, off);
     cnt.prim += __shfl_down(cnt.prim, off);
