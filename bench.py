@@ -13,7 +13,7 @@ Prints ONE JSON line on rank 0 (metric = whole-job path-samples/s).  Besides the
                 vector-ALU issue: lane-operations per second against the nominal peak (the rate of plain f32
                 multiply-adds), and under `issue` the occupancy of the issue port once every instruction is priced at
                 the cost measured for its kind.  The work per ray segment comes from a committed
-                rocprofv3 PMC summary (profiles/r02/roofline_profile.json, with the git hash it was taken at and the
+                rocprofv3 PMC summary (profiles/r03/roofline_profile.json, with the git hash it was taken at and the
                 hash of the kernel source it describes); the segments and the launch durations are measured live.
   roofline_s5   the same kernel on the one configuration whose scene tables do not fit the caches (the 100^3
                 OpenSCAD-shaped instance lattice), against HBM bandwidth: algorithmic node / instance bytes per
@@ -50,7 +50,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 # little more than half that rate (tools/micro/valu_clock measures both; the profile carries the figures), so the
 # kernel's own instruction mix cannot reach this peak: `issue` below prices the mix.
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-PROFILE_JSON = os.path.join(ROOT, "profiles", "r02", "roofline_profile.json")
+PROFILE_JSON = os.path.join(ROOT, "profiles", "r03", "roofline_profile.json")
 KERNEL_SOURCES = [os.path.join(ROOT, "rust-raytracer_amd", "csrc", f) for f in ("kernels.hpp", "device_scene.h")]
 
 
@@ -280,7 +280,8 @@ def main():
         usable = bool(ops_per_seg) and not prof_note and default_workload
         achieved = ops_per_seg * seg / (ms_trace * 1e-3) / 1e12 if (usable and ms_trace > 0) else None
         roofline = {
-            "kernel": "k_extend_small<*> (ordered closest-hit traversal, compact form: f32 culling of 4-wide nodes, f64 sphere tests, scene tables in LDS)",
+            "kernel": "k_first_small<true> (bounce 0: camera ray, closest hit and the lean material code in one kernel) + k_extend_small<false> (closest hit of "
+                      "later bounces): ordered traversal, compact form, f32 culling of 4-wide nodes, f64 sphere tests, scene tables in LDS",
             "bound": "valu",
             "achieved": achieved,
             "peak": VALU_PEAK_TLANEOPS,

@@ -1,9 +1,10 @@
 #!/bin/bash
 # Collects the PMC passes behind bench.py's roofline objects (one rocprofv3 run per pass; slot limits: 8 SQ, 4 TCC)
-# and writes profiles/r02/roofline_profile.json + the per-kernel counter summaries.  Run on the GPU box:
-#   tools/collect_roofline_profile.sh <git-hash>
+# and writes profiles/$ROUND/roofline_profile.json + the per-kernel counter summaries.  Run on the GPU box:
+#   tools/collect_roofline_profile.sh <git-hash> [round]
 set -u
 GIT="${1:-unknown}"
+ROUND="${2:-r03}"
 ROOT="$GRAFT_REPO_ROOT"
 OUT="$ROOT/gpurun_out/roofline_profile"
 rm -rf "$OUT"; mkdir -p "$OUT/s2" "$OUT/s5"

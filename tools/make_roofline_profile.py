@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the PMC summaries collected by tools/collect_roofline_profile.sh into profiles/r02/roofline_profile.json, the
+"""Turns the PMC summaries collected by tools/collect_roofline_profile.sh into profiles/<round>/roofline_profile.json, the
 per-ray-segment figures bench.py multiplies with its live segment counts and launch durations.
 usage: make_roofline_profile.py <dir with pmc_s2_summary.txt, pmc_s5_summary.txt, s2/*.log, s5/*.log> <git hash>"""
 import datetime
@@ -99,8 +99,16 @@ def main():
     b = last_json(os.path.join(d, "s2", "sq.log"))
     seg2 = b["roofline"]["segments_per_path"] * b["config"]["path_samples_per_step"] * b["steps"]
     cost = issue_costs(os.path.join(d, "valu_issue_cost.txt"))
-    s2 = figures(counters(os.path.join(d, "pmc_s2_summary.txt"), ("k_extend_small<", "k_extend<0u, true, true")), seg2, cost)
+    # the kernels that trace the frame's segments: bounce 0 in k_first_small (which also shades its hits), later bounces in
+    # k_extend_small (k_extend<0, true, true, *> when the scene is too large for the compact form)
+    s2 = figures(counters(os.path.join(d, "pmc_s2_summary.txt"), ("k_first_small<", "k_extend_small<", "k_extend<0u, true, true")), seg2, cost)
     s2["workload"] = b["config"]["workload"] + " (one frame under rocprofv3 --pmc, kernels serialised)"
+    s2["kernels"] = "k_first_small<true> (bounce 0: camera ray, closest hit and the lean material code) + k_extend_small<false> (closest hit of later bounces)"
+    # the same for the later bounces' kernel alone (closest hit only)
+    c_later = counters(os.path.join(d, "pmc_s2_summary.txt"), ("k_extend_small<false", "k_extend<0u, true, true, false"))
+    seg_later = seg2 - b["config"]["path_samples_per_step"] * b["steps"]  # every path has one segment at bounce 0
+    if c_later and seg_later > 0:
+        s2["later_bounces_only"] = figures(c_later, seg_later, cost)
     l = last_json(os.path.join(d, "s5", "sq.log"))
     seg5 = 2 * l["segments_per_path"] * 1920 * 1080 * l["spp"]  # run_configs renders the frame twice
     s5 = figures(counters(os.path.join(d, "pmc_s5_summary.txt"), ("k_extend<35u, true, true",)), seg5, cost)
