@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--s5-n", type=int, default=100)
     ap.add_argument("--s5-spp", type=int, default=64)
     ap.add_argument("--no-rank-share", action="store_true", help="skip timing one rank's share of an 8-GPU job")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the extra one-stream frame that gives exclusive kernel times (counter runs: every frame rendered counts)")
     ap.add_argument("--simulate-rank-of", type=int, default=8, help="ranks of the job whose per-rank share is timed on this GPU")
     args = ap.parse_args()
 
@@ -322,6 +323,8 @@ def main():
         # time on two streams, where a launch's event interval includes time it shared with the other batch's kernels.
         exclusive = None
         try:
+            if args.no_exclusive:
+                raise RuntimeError("skipped (--no-exclusive)")
             os.environ["CHIP_STREAMS"] = "1"
             ex_stats = []
             ex_step = make_step(world, rank, False, flags=pkg.bindings.RENDER_TIME_KERNELS, stats_out=ex_stats)

@@ -16,7 +16,7 @@ pass() {  # pass <subdir> <name> <counters...> -- <program args...>
   shift
   timeout -s KILL 300 rocprofv3 --pmc "${ctrs[@]}" --output-format csv -d "$OUT/$sub/$name" -o p -- python3 "$@" > "$OUT/$sub/$name.log" 2>&1 || { echo "pass $sub/$name failed"; tail -3 "$OUT/$sub/$name.log"; return 1; }
 }
-S2="$ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-s5 --no-rank-share"
+S2="$ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-s5 --no-rank-share --no-exclusive"
 S5="$ROOT/tools/run_configs.py lattice:100"
 pass s2 sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -- $S2 &&
 pass s2 fetch FETCH_SIZE GRBM_GUI_ACTIVE -- $S2 &&
