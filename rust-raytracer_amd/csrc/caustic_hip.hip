@@ -163,6 +163,7 @@ struct DeviceState {
   DevBuf<uint8_t> d_texels;
   DevBuf<DLight> d_lights;
   DevBuf<DLightNode> d_ltree;
+  DevBuf<DFlatPrim> d_flat;
   DScene dscene;
   PoolBufs pools[kMaxLanes];
   LaneRes lanes[kMaxLanes];
@@ -180,7 +181,7 @@ struct DeviceState {
   void release_tables() {
     d_bvh.release(); d_wnodes.release(); d_spheres.release(); d_quads.release(); d_groups.release(); d_gchild.release();
     d_translates.release(); d_rotates.release(); d_scales.release(); d_discs.release(); d_cones.release(); d_media.release(); d_xchain.release(); d_materials.release();
-    d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release(); d_ltree.release();
+    d_textures.release(); d_perlins.release(); d_texels.release(); d_lights.release(); d_ltree.release(); d_flat.release();
     uploaded = false;
   }
   // (with this state's device current)
@@ -399,7 +400,7 @@ struct ExtendPlan {
 static const uint32_t kLdsBytes = 160 * 1024;
 // Tuning knobs read from the environment, once per render call (tests change them between calls of one process).
 struct EnvKnobs {
-  bool no_lds_cache = false, no_small = false;
+  bool no_lds_cache = false, no_small = false, no_flat = false;
   int lds_stack = 0;          // 0 = the variant's default
   uint32_t small_stack = 16;  // stack words per lane of the compact form
   uint32_t small_queue = 16384;
@@ -407,6 +408,7 @@ struct EnvKnobs {
     EnvKnobs k;
     if (const char* e = getenv("CHIP_NO_LDS_CACHE")) k.no_lds_cache = *e == '1';
     if (const char* e = getenv("CHIP_NO_SMALL_FORM")) k.no_small = *e == '1';
+    if (const char* e = getenv("CHIP_NO_FLAT_FORM")) k.no_flat = *e == '1';
     if (const char* e = getenv("CHIP_LDS_STACK")) { int v = atoi(e); if (v >= 2 && v <= 16) k.lds_stack = v; }
     if (const char* e = getenv("CHIP_SMALL_STACK")) { int v = atoi(e); if (v >= 4 && v <= 24) k.small_stack = (uint32_t)v; }
     if (const char* e = getenv("CHIP_SMALL_QUEUE")) { if (*e) k.small_queue = (uint32_t)atol(e); }
@@ -457,6 +459,7 @@ struct ExtendPlans {
   ExtendPlan full;       // long queues: the LDS-cached form when the scene has one
   ExtendPlan shortq;     // short queues (the late bounces)
   uint32_t small_queue;  // queues below this many entries are short
+  bool flat;             // the world is tried as a list of primitives (k_extend_flat)
 };
 template <uint32_t F, bool CACHE, bool ORD, bool B0>
 static int launch_extend_b(const DeviceState& D, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
@@ -563,6 +566,10 @@ static ExtendPlans plan_extends(const chip_scene* s, uint32_t scene_feat) {
   // and Cornell scenes).  Not for instanced spheres: their deep trees want the cached top levels even then.
   X.shortq = (X.feat & TF_NO_QUADROT) ? X.full : X.lit;
   X.small_queue = env.small_queue;
+  // a few spheres and quads: the flat form (CHIP_NO_FLAT_FORM=1 keeps the hierarchy walk: tests compare the two)
+  // (bare spheres walk their LDS-resident tree well: only a handful of them is faster as a list)
+  X.flat = !env.no_flat && !s->flat.flat_list.empty() && !s->flat.loose_geometry && (X.feat & ~(TF_QUADS | TF_XFORM)) == 0u &&
+           (X.feat != 0u || s->flat.flat_list.size() <= 8);
   return X;
 }
 // Whether bounce 0 runs in one kernel (k_first_small): small scenes of bare spheres (the compact form of the traversal)
@@ -595,6 +602,19 @@ static int launch_extend(const DeviceState& D, const PathPool& P, const ExtendPl
     int rc_ = launch_first_small(D, P, X.full, n_live_upper, st, B, fused_first == 2, waste_out);
     if (rc_) return rc_;
     return launch_extend_t<0, false, false>(D, P, lit, lit_upper, st, B, bounce, 1);
+  }
+  if (X.flat && !B.reference_order) {
+    if (D.dscene.n_flat == 0u || D.dscene.n_flat > CHIP_FLAT_MAX) return fail("internal: flat traversal planned for a scene without a primitive list");
+    uint32_t blocks = (n_live_upper + CHIP_FLAT_BLOCK - 1) / CHIP_FLAT_BLOCK;
+    blocks = std::max(1u, std::min(blocks, (uint32_t)D.n_cus * 32u));
+    if (bounce == 0) hipLaunchKernelGGL((k_extend_flat<true>), dim3(blocks), dim3(CHIP_FLAT_BLOCK), 0, st, D.dscene, P, B, bounce);
+    else hipLaunchKernelGGL((k_extend_flat<false>), dim3(blocks), dim3(CHIP_FLAT_BLOCK), 0, st, D.dscene, P, B, bounce);
+    switch (feat) {  // the literal pass over the rays handed back (normally none)
+      case 0: return launch_extend_t<0, false, false>(D, P, lit, lit_upper, st, B, bounce, 1);
+      case TF_QUADS: return launch_extend_t<TF_QUADS, false, false>(D, P, lit, lit_upper, st, B, bounce, 1);
+      case TF_QUADS | TF_XFORM: return launch_extend_t<TF_QUADS | TF_XFORM, false, false>(D, P, lit, lit_upper, st, B, bounce, 1);
+      default: return fail("internal: flat traversal planned for a scene it does not cover");
+    }
   }
   if (feat == 0 && p.cache && p.small) {
     int rc_ = bounce == 0 ? launch_extend_small<true>(D, P, p, n_live_upper, st, B, bounce) : launch_extend_small<false>(D, P, p, n_live_upper, st, B, bounce);
@@ -977,6 +997,7 @@ static int upload_scene(chip_scene* s, DeviceState& D, const Flat& F) {
   HIP_TRY(D.d_texels.upload(s->host.texels));
   HIP_TRY(D.d_lights.upload(F.lights));
   HIP_TRY(D.d_ltree.upload(F.ltree));
+  HIP_TRY(D.d_flat.upload(F.flat_list));
   DScene& T = D.dscene;
   T.bvh = D.d_bvh.p; T.wnodes = D.d_wnodes.p; T.spheres = D.d_spheres.p; T.quads = D.d_quads.p; T.groups = D.d_groups.p; T.gchild = D.d_gchild.p;
   T.translates = D.d_translates.p; T.rotates = D.d_rotates.p; T.scales = D.d_scales.p; T.discs = D.d_discs.p; T.cones = D.d_cones.p;
@@ -984,6 +1005,8 @@ static int upload_scene(chip_scene* s, DeviceState& D, const Flat& F) {
   T.materials = D.d_materials.p; T.textures = D.d_textures.p; T.perlins = D.d_perlins.p; T.texels = D.d_texels.p;
   T.lights = D.d_lights.p;
   T.ltree = D.d_ltree.p;
+  T.flat_list = D.d_flat.p;
+  T.n_flat = (uint32_t)F.flat_list.size();
   T.root = F.root;
   T.ord_root = F.ord_root;
   T.n_lights = (uint32_t)F.lights.size();

@@ -197,6 +197,17 @@ struct DLightNode {
   uint32_t leaf;
 };
 
+// A scene of a few primitives as a list (the flat form of the traversal): every sphere and quad of the world with the
+// transform it sits under, primitives of one transform in a row.  `enter` is set on the first primitive of each
+// such run: the ray is taken into that space there.
+#define CHIP_FLAT_MAX 32
+struct alignas(16) DFlatPrim {
+  nref_t ref;
+  nref_t xform;  // innermost transform ancestor, or NREF_NONE
+  uint32_t enter;
+  uint32_t pad;
+};
+
 struct DCamera {  // Camera, camera.rs:202-231
   double center[3], pixel00[3], du[3], dv[3], disk_u[3], disk_v[3];
   double background[3];
@@ -224,6 +235,8 @@ struct DScene {
   const uint8_t* texels;
   const DLight* lights;
   const DLightNode* ltree;
+  const DFlatPrim* flat_list;  // n_flat entries; n_flat == 0: the scene has no flat form
+  uint32_t n_flat;
   nref_t root;
   nref_t ord_root;  // the ordered traversal's starting node (differs from root when that is a Group)
   uint32_t n_lights;

@@ -2205,6 +2205,129 @@ __global__ void __launch_bounds__(extend_block(0, true), extend_min_waves(0, tru
   }
 }
 
+// ------------------------------------------------------------------ flat form for scenes of a few primitives
+// A world of a few spheres and quads (DScene::flat_list: the Cornell box and its kin) is not walked but tried whole:
+// every lane takes one ray through the same list, in step, so the primitive's record comes through scalar loads and
+// no lane waits for another one's node kind (the hierarchy walk of such a scene runs at a third of its lanes).  The
+// tests and the arithmetic are those of the ordered traversal: inclusive intervals, exact ties settled by the
+// reference's visiting order, the ray taken into an instance's space by replaying its transform chain; a ray with a
+// direction component that is zero (in the world or in an instance's space) goes to the literal pass, as it does
+// there, because the reference's box tests decide by the sign of such a zero.
+#define CHIP_FLAT_BLOCK 256
+// The scene tables are read-only while a kernel runs, but the compiler cannot know that (the kernel also stores through
+// pointers) and would fetch a record with one vector load per lane although every lane reads the same one.  Read through
+// a pointer to the constant address space, a record at a wave-uniform index comes through the scalar unit into scalar
+// registers, once per wave.
+#define CHIP_KCONST(T, ptr) (reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(ptr)))
+// ray_to_space for Translates and Rotates, on scalar loads
+__device__ inline void flat_to_space(const DScene& S, nref_t x, V3 wo, V3 wd, V3& o, V3& d) {
+  o = wo; d = wd;
+  uint32_t first, n;
+  if (NREF_KIND(x) == NK_TRANSLATE) { first = CHIP_KCONST(DTranslate, S.translates)[NREF_INDEX(x)].chain_first; n = CHIP_KCONST(DTranslate, S.translates)[NREF_INDEX(x)].chain_len; }
+  else { first = CHIP_KCONST(DRotate, S.rotates)[NREF_INDEX(x)].chain_first; n = CHIP_KCONST(DRotate, S.rotates)[NREF_INDEX(x)].chain_len; }
+  for (uint32_t i = 0; i < n; i++) {
+    const nref_t c = CHIP_KCONST(nref_t, S.xchain)[first + i];
+    if (NREF_KIND(c) == NK_TRANSLATE) {
+      const auto* t = CHIP_KCONST(DTranslate, S.translates) + NREF_INDEX(c);
+      o = o - mk(t->off[0], t->off[1], t->off[2]);
+    } else {
+      const auto* t = CHIP_KCONST(DRotate, S.rotates) + NREF_INDEX(c);
+      double m[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) m[k] = t->m[k];
+      o = mat_mulT(m, o);
+      d = mat_mulT(m, d);
+    }
+  }
+}
+template <bool B0>
+__global__ void __launch_bounds__(CHIP_FLAT_BLOCK) k_extend_flat(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg) {
+  const uint32_t bounce = B0 ? 0u : bounce_arg;
+  uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
+  const uint32_t n_live = ctr[0];
+  const PathRay* ray_in = P.ray[bounce & 1];
+  const bool r48 = B.ray48 != 0u;
+  const uint32_t n_flat = S.n_flat;
+  uint32_t nseg = 0, ntest = 0;
+  for (uint32_t entry = blockIdx.x * blockDim.x + threadIdx.x; entry < n_live; entry += gridDim.x * blockDim.x) {
+    TravRay r;
+    uint32_t id = entry, tries = 0;
+    if (B0) path_camera_ray(S, B, entry, r.wo, r.wd, r.time, tries);
+    else ray_load(ray_in, entry, r48, r.wo, r.wd, r.time, id);
+    if (!B0 && id == CHIP_DEAD_ID) {  // reserved by the last shading pass but left empty
+      *reinterpret_cast<uint4*>(P.hit + entry) = make_uint4(0u, 0u, NREF_DEAD, 0u);
+      continue;
+    }
+    bool literal = has_zero_component(r.wd);
+#ifdef CHIP_TEST_HAND_OVER
+    literal = literal || entry % CHIP_TEST_HAND_OVER == 0u;
+#endif
+    r.o = r.wo; r.d = r.wd;
+    r.dd = len2(r.d);
+    double best_t = INFINITY;
+    nref_t best = NREF_NONE;
+    uint32_t best_mat = 0;
+    for (uint32_t i = 0; i < n_flat; i++) {
+      const auto* fe = CHIP_KCONST(DFlatPrim, S.flat_list) + i;
+      DFlatPrim e;
+      e.ref = fe->ref; e.xform = fe->xform; e.enter = fe->enter;
+      if (e.enter) {
+        flat_to_space(S, e.xform, r.wo, r.wd, r.o, r.d);
+        literal = literal || has_zero_component(r.d);
+        r.dd = len2(r.d);
+      }
+      const uint32_t idx = NREF_INDEX(e.ref);
+      double t;
+      bool hit;
+      uint32_t matw;
+      if (NREF_KIND(e.ref) == NK_SPHERE) {
+        const auto* rec = CHIP_KCONST(DSphere, S.spheres) + idx;
+        SphereRec sp;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { sp.c[k] = rec->c[k]; sp.dc[k] = rec->dc[k]; }
+        sp.r = rec->r;
+        sp.mat = rec->mat;
+        hit = sphere_hit_incl(sp, r, 0.001, best_t, t);
+        matw = sp.mat;
+      } else {
+        const auto* rec = CHIP_KCONST(DQuad, S.quads) + idx;
+        DQuad q;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { q.q[k] = rec->q[k]; q.u[k] = rec->u[k]; q.v[k] = rec->v[k]; q.n[k] = rec->n[k]; q.w[k] = rec->w[k]; }
+        q.d = rec->d;
+        q.mat = rec->mat;
+        double al, be;
+        hit = quad_hit_od(q, r.o, r.d, 0.001, best_t, t, al, be);
+        matw = q.mat;
+      }
+      if (hit && (t < best_t || tie_wins(S, e.ref, best))) {
+        best_t = t;
+        best = e.ref;
+        best_mat = matw;
+      }
+    }
+    if (literal) {
+      P.q_lit[atomicAdd(&ctr[CHIP_CTR_LIT], 1u)] = entry;
+    } else {
+      nseg++;
+      ntest += n_flat;
+      PathHit ph;
+      ph.t = best_t;
+      ph.node = best;
+      ph.info = (best_mat & 0xFFFFFFu) | (B0 ? (tries << 24) : 0u);
+      *reinterpret_cast<uint4*>(P.hit + entry) = *reinterpret_cast<const uint4*>(&ph);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    ntest += __shfl_down(ntest, off);
+    nseg += __shfl_down(nseg, off);
+  }
+  if (__lane_id() == 0 && nseg) {
+    atomicAdd(&P.stats[0], (unsigned long long)nseg);
+    atomicAdd(&P.stats[2], (unsigned long long)ntest);
+  }
+}
+
 // One hit of one path: Material::emitted / scatter / scattering_pdf of material kind KIND plus the PDF
 // branch of camera.rs:278-305.  The segment's ray (ro, rd, rtime) and closest hit (ph) come from the
 // caller.  Returns true with the next ray and the bounce's map x -> clamp(xw x, klo, khi) if the material

@@ -106,6 +106,7 @@ struct Flat {
   uint32_t has_lights = 0, lights_is_group = 0;
   uint32_t loose_geometry = 0;  // some primitive of the world is not bounded by its own box
   uint32_t nonunit_normals = 0;  // some Disc keeps a normal that is not of unit length (Disc::new stores it as given, disc.rs:24-41)
+  std::vector<DFlatPrim> flat_list;  // the world as a list of primitives, when it is small enough (build_flat_list)
   uint32_t n_wide = 0;          // culling nodes in use: wnodes[0 .. n_wide)
   nref_t ord_root = NREF_NONE;  // where the ordered traversal starts: root, or the culling tree of a Group root's children
 };
@@ -707,6 +708,7 @@ struct HostScene {
     if (!has_camera) throw std::runtime_error("scene has no camera");
     Flattener fl(*this, F);
     F.root = fl.emit(handle[world], NREF_NONE, false, -1);
+    build_flat_list(F);  // (before the lights add their own copies of primitives to the tables)
     if (lights >= 0) {
       F.has_lights = 1;
       const HNode& L = nodes[handle[lights]];
@@ -723,6 +725,32 @@ struct HostScene {
     build_wnodes(F);
     if (F.bvh.size() >= (1u << 28) || F.spheres.size() >= (1u << 28) || F.quads.size() >= (1u << 28) || F.discs.size() >= (1u << 28) || F.cones.size() >= (1u << 28))
       throw std::runtime_error("scene too large for 28-bit node indices");
+  }
+
+  // The flat form: a world of at most CHIP_FLAT_MAX spheres and quads, under Translates and Rotates or under nothing, is
+  // also kept as a plain list.  The closest hit does not depend on the order primitives are tried in once exact ties go by
+  // the reference's visiting order, and testing a primitive whose enclosing boxes the ray misses finds nothing (the boxes
+  // contain it), so a kernel may try the whole list for every ray, all lanes in step, instead of walking hierarchies
+  // lane by lane.  Called when the tables hold the world's primitives only.
+  static void build_flat_list(Flat& F) {
+    F.flat_list.clear();
+    const size_t n = F.spheres.size() + F.quads.size();
+    if (n == 0 || n > CHIP_FLAT_MAX) return;
+    if (!F.media.empty() || !F.discs.empty() || !F.cones.empty() || !F.scales.empty()) return;
+    std::vector<DFlatPrim> list;
+    for (size_t i = 0; i < F.quads.size(); i++) list.push_back(DFlatPrim{NREF(NK_QUAD, i), F.quads[i].xform, 0u, 0u});
+    for (size_t i = 0; i < F.spheres.size(); i++) list.push_back(DFlatPrim{NREF(NK_SPHERE, i), F.spheres[i].xform, 0u, 0u});
+    // world space first (NREF_NONE is the largest reference: mapped to 0 for the ordering), then one transform after the other
+    std::stable_sort(list.begin(), list.end(), [](const DFlatPrim& a, const DFlatPrim& b) {
+      const uint64_t ka = a.xform == NREF_NONE ? 0 : (uint64_t)a.xform + 1, kb = b.xform == NREF_NONE ? 0 : (uint64_t)b.xform + 1;
+      return ka < kb;
+    });
+    nref_t cur = NREF_NONE;
+    for (DFlatPrim& e : list) {
+      e.enter = e.xform != cur ? 1u : 0u;
+      cur = e.xform;
+    }
+    F.flat_list.swap(list);
   }
 
   // Renumbers the BVH table breadth-first (world root first, then nested BVHs in order of discovery) so

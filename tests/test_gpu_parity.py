@@ -883,6 +883,36 @@ def test_first_bounce_in_one_kernel_equals_two_kernel_form(pkg, gpu, oracle, mon
 
 
 @pytest.mark.gpu
+def test_flat_form_equals_the_hierarchy_walk(pkg, gpu, oracle, monkeypatch):
+    """A world of at most 32 spheres and quads under Translates and Rotates (the Cornell box, the quads scene, a sphere
+    or two with a light) is traced by trying every primitive for every ray, all lanes in step (k_extend_flat);
+    CHIP_NO_FLAT_FORM=1 keeps the walk through the culling trees.  The closest hit and its tie rule are the same, so
+    images and segment counts are the same bits in both shading modes; the flat form is also compared with the oracle."""
+    monkeypatch.delenv("CHIP_NO_FLAT_FORM", raising=False)
+    X = pkg.bindings.RENDER_EXACT_SHADING
+    for name, kw, seed in (("cornell_box", dict(width=120, spp=16, depth=12), 3), ("quads", dict(width=120, spp=9, depth=8), 2),
+                           ("lighted_sphere", dict(width=120, spp=9, depth=8), 4), ("earth", dict(width=96, spp=4, depth=4), 1),
+                           ("perlin_spheres", dict(width=96, spp=4, depth=6), 5), ("cornell_box", dict(width=600, spp=4, depth=50), 1)):
+        sc = pkg.scenes.build(gpu, name, **kw)
+        for flags in (0, X):
+            flat, _, st1 = sc.render_frame(seed=seed, flags=flags)
+            monkeypatch.setenv("CHIP_NO_FLAT_FORM", "1")
+            walk, _, st2 = sc.render_frame(seed=seed, flags=flags)
+            monkeypatch.delenv("CHIP_NO_FLAT_FORM")
+            assert st1["segments"] == st2["segments"] and st1["paths"] == st2["paths"], (name, kw, flags)
+            # (the flat form is the one that ran; the earth scene is one bare sphere, with no hierarchy to visit either way)
+            assert st1["bvh_visits"] == 0 and (st2["bvh_visits"] > 0 or name == "earth"), (name, kw, flags)
+            assert np.array_equal(flat.view(np.uint32), walk.view(np.uint32)), (name, kw, flags)
+    so = pkg.scenes.build(oracle, "cornell_box", width=64, spp=4, depth=10)
+    sg = pkg.scenes.build(gpu, "cornell_box", width=64, spp=4, depth=10)
+    img_o, _, st_o = so.render_frame(seed=7, sum_dtype=np.float64)
+    img_g, _, st_g = sg.render_frame(seed=7, flags=X)
+    assert st_g["segments"] == st_o["segments"] and st_g["bvh_visits"] == 0
+    diff = np.abs(img_g.astype(np.float64) - img_o)
+    assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
+
+
+@pytest.mark.gpu
 def test_literal_hand_over_of_every_fifth_ray(pkg, gpu):
     """The ordered traversal hands a ray it cannot take (a zero direction component, a descent deeper than the compact
     form's stack) to the literal traversal, which runs as a pass of its own after it: a ray or two per frame in the
