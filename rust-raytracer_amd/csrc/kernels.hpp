@@ -924,18 +924,26 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       if (descend != NREF_NONE) { node = descend; continue; }
     } else if ((F & TF_XFORM) && kind == NK_TRANSLATE) {
       const DTranslate& t = S.translates[idx];
-      if (t.only_sphere != NREF_NONE) {
+      nref_t only = t.only_sphere;
+      V3 toff = ld3(t.off);
+      SphereRec sp;
+      sp.c[0] = t.sc[0]; sp.c[1] = t.sc[1]; sp.c[2] = t.sc[2];
+      sp.dc[0] = t.sdc[0]; sp.dc[1] = t.sdc[1]; sp.dc[2] = t.sdc[2];
+      sp.r = t.sr;
+      sp.mat = t.sphere_mat;
+      // Instanced-sphere scenes: everything the test below reads is asked for here, before the branch on what the
+      // Translate holds (left alone, the compiler loads that word, waits, branches and only then asks for the rest of
+      // the same record: two trips to memory one after the other).
+      if (F & TF_NO_QUADROT)
+        asm volatile("" : "+v"(only), "+v"(toff.x), "+v"(toff.y), "+v"(toff.z), "+v"(sp.c[0]), "+v"(sp.c[1]), "+v"(sp.c[2]), "+v"(sp.dc[0]), "+v"(sp.dc[1]),
+                         "+v"(sp.dc[2]), "+v"(sp.r), "+v"(sp.mat));
+      if (only != NREF_NONE) {
         // A Translate around a single sphere (translate.rs:26-38 over group.rs:44-54 over sphere.rs:99-121): the same
         // arithmetic on the offset origin, without entering and leaving the instance on the stack.
         // The sphere's geometry rides in the Translate's own record (one 128-byte fetch instead of two dependent ones).
         const V3 outer_o = r.o;
-        r.o = r.o - ld3(t.off);
-        const nref_t c = t.only_sphere;
-        SphereRec sp;
-        sp.c[0] = t.sc[0]; sp.c[1] = t.sc[1]; sp.c[2] = t.sc[2];
-        sp.dc[0] = t.sdc[0]; sp.dc[1] = t.sdc[1]; sp.dc[2] = t.sdc[2];
-        sp.r = t.sr;
-        sp.mat = t.sphere_mat;
+        r.o = r.o - toff;
+        const nref_t c = only;
         double tt;
         cnt.prim++;
         if (ORD ? sphere_hit_incl(sp, r, tmin, best_t, tt) : sphere_hit(sp, r, tmin, best_t, tt)) { CHIP_TAKE(c, tt, sp.mat) }
