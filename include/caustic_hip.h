@@ -149,6 +149,9 @@ int chip_scale(chip_scene* s, int node, double sx, double sy, double sz);       
 int chip_disc(chip_scene* s, const double center[3], double radius, const double normal[3], int mat); /* disc.rs:24-54 */
 /* ConeFrustum::new: top disc and bottom disc (each only when its radius > 1e-4) and the side wall, as a Group. */
 int chip_cone_frustum(chip_scene* s, const double base[3], double height, double top_radius, double bottom_radius, int mat); /* cone.rs:19-75 */
+/* The boundary may be any node (constant_medium.rs:19-29), media included one level deep: a medium inside a boundary
+ * must itself be bounded by a sphere or a box and must not hold media in its own boundary (chip_commit reports the
+ * shapes beyond that as errors). */
 int chip_constant_medium_color(chip_scene* s, int boundary, double density, double r, double g, double b); /* constant_medium.rs:31-37 */
 int chip_constant_medium_tex(chip_scene* s, int boundary, double density, int tex);        /* constant_medium.rs:19-29 */
 

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <stdexcept>
 #include <vector>
 
 namespace orc {
@@ -204,6 +205,9 @@ struct RenderContext {  // lib.rs:34-36
   // depends on the visiting order, so only the reference-order recursion can use it); 2 = a single keyed sample
   // whatever the number of tests, a deliberately wrong form that tests use as a negative control.
   int media_mode = 0;
+  // With keyed samples: which boundary query of the enclosing medium is being answered (see ConstantMedium, nested
+  // form); 0 outside of any boundary.
+  uint32_t medium_ctx = 0;
 };
 
 // vector.rs:63-69
@@ -1207,48 +1211,83 @@ struct ConstantMedium : Node {
   // one ray draw independently, as they do from the reference's stream.
   int tests = 0;
   uint32_t sample_base = 0;
+  // A boundary may hold media of its own (constant_medium.rs:19-29 takes any node).  Every test of this medium then
+  // asks the boundary twice, and each query makes the media inside draw afresh, so the tests cannot be folded into one
+  // "nearest of `tests` samples": with keyed samples hit() runs them one after the other over the shrinking interval,
+  // as the reference's recursion does, and a medium inside the boundary owns a run of its `tests` keys per query
+  // (`queries` = 2 x this medium's tests; query q of test k is context 2k + q, RenderContext::medium_ctx).  One level
+  // of nesting, like the device.
+  bool nested = false;
+  uint32_t queries = 1;  // for a medium inside a boundary: boundary queries per world.hit of the enclosing medium
+  static uint32_t& numbering_queries() { static thread_local uint32_t q = 0; return q; }
   void count_tests(int v) override { tests += v; }
   bool holds_medium() const override { return true; }
   NodeP instantiate(const NodeP&) const override {
     auto c = std::make_shared<ConstantMedium>(*this);
     c->tests = 0;
+    if (boundary->holds_medium()) {
+      c->boundary = boundary->instantiate(boundary);
+      c->nested = true;
+    }
     return c;
   }
   void number_media(uint32_t& next) override {
+    const uint32_t outer = numbering_queries();
+    queries = outer ? outer : 1u;
     sample_base = next;
-    next += (uint32_t)tests;
+    next += (uint32_t)tests * queries;
+    if (nested) {
+      if (outer) throw std::runtime_error("a ConstantMedium whose boundary holds media, inside another medium's boundary, is not supported (one level of nesting)");
+      boundary->count_tests(1);
+      numbering_queries() = 2u * (uint32_t)tests;
+      boundary->number_media(next);
+      numbering_queries() = outer;
+    }
   }
   // constant_medium.rs:41-80
   bool hit(RenderContext& ctx, const Ray& ray, Interval ray_t, HitRecord& rec) const override {
-    HitRecord hit1, hit2;
-    if (!boundary->hit(ctx, ray, universe(), hit1)) return false;
-    if (!boundary->hit(ctx, ray, Interval(hit1.t + 0.0001, kInf), hit2)) return false;
-    if (hit1.t < ray_t.min) hit1.t = ray_t.min;
-    if (hit2.t > ray_t.max) hit2.t = ray_t.max;
-    if (hit1.t >= hit2.t) return false;
-    if (hit1.t < 0.0) hit1.t = 0.0;
-    double ray_length = ray.direction.length();
-    double distance_inside_boundary = (hit2.t - hit1.t) * ray_length;
-    double u;
-    if (ctx.media_mode == 1) {
-      u = ctx.random->rand();  // constant_medium.rs:64
-    } else {
-      u = ctx.random->rand_keyed(sample_base);
-      if (ctx.media_mode == 0)
-        for (int j = 1; j < tests; j++) u = std::fmax(u, ctx.random->rand_keyed(sample_base + (uint32_t)j));
+    const bool one_by_one = nested && ctx.media_mode == 0;
+    const int reps = one_by_one ? tests : 1;
+    const uint32_t outer_ctx = ctx.medium_ctx;
+    bool any = false;
+    for (int rep = 0; rep < reps; rep++) {
+      HitRecord hit1, hit2;
+      if (one_by_one) ctx.medium_ctx = 2u * (uint32_t)rep;
+      const bool got1 = boundary->hit(ctx, ray, universe(), hit1);
+      if (one_by_one) ctx.medium_ctx = 2u * (uint32_t)rep + 1u;
+      const bool got2 = got1 && boundary->hit(ctx, ray, Interval(hit1.t + 0.0001, kInf), hit2);
+      ctx.medium_ctx = outer_ctx;
+      if (!got2) continue;
+      if (hit1.t < ray_t.min) hit1.t = ray_t.min;
+      if (hit2.t > ray_t.max) hit2.t = ray_t.max;
+      if (hit1.t >= hit2.t) continue;
+      if (hit1.t < 0.0) hit1.t = 0.0;
+      double ray_length = ray.direction.length();
+      double distance_inside_boundary = (hit2.t - hit1.t) * ray_length;
+      double u;
+      if (ctx.media_mode == 1) {
+        u = ctx.random->rand();  // constant_medium.rs:64
+      } else {
+        const uint32_t key0 = sample_base + outer_ctx * (uint32_t)tests;
+        u = ctx.random->rand_keyed(one_by_one ? key0 + (uint32_t)rep : key0);
+        if (ctx.media_mode == 0 && !one_by_one)
+          for (int j = 1; j < tests; j++) u = std::fmax(u, ctx.random->rand_keyed(key0 + (uint32_t)j));
+      }
+      double hit_distance = neg_inv_density * std::log(u);
+      if (hit_distance > distance_inside_boundary) continue;
+      double t = hit1.t + hit_distance / ray_length;
+      rec.pt = ray.at(t);
+      rec.normal = Vec3(1.0, 0.0, 0.0);
+      rec.t = t;
+      rec.u = 0.0;
+      rec.v = 0.0;
+      rec.front_face = true;
+      rec.material = phase_function.get();
+      rec.leaf_id = id;
+      ray_t.max = t;
+      any = true;
     }
-    double hit_distance = neg_inv_density * std::log(u);
-    if (hit_distance > distance_inside_boundary) return false;
-    double t = hit1.t + hit_distance / ray_length;
-    rec.pt = ray.at(t);
-    rec.normal = Vec3(1.0, 0.0, 0.0);
-    rec.t = t;
-    rec.u = 0.0;
-    rec.v = 0.0;
-    rec.front_face = true;
-    rec.material = phase_function.get();
-    rec.leaf_id = id;
-    return true;
+    return any;
   }
   const AABB& bounding_box() const override { return boundary->bounding_box(); }
 };

@@ -273,7 +273,12 @@ int orc_scene_set_world(OrcScene* s, int node) {
   s->world = s->nodes[node]->instantiate(s->nodes[node]);
   s->world->count_tests(1);
   uint32_t next_sample = 0;
-  s->world->number_media(next_sample);
+  try {
+    s->world->number_media(next_sample);
+  } catch (const std::exception& e) {
+    s->world.reset();
+    return fail(e.what());
+  }
   return 0;
 }
 int orc_scene_set_lights(OrcScene* s, int node) {

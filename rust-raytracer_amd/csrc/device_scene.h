@@ -151,7 +151,10 @@ struct alignas(8) DMedium {
   // in the space of transform bx_inner (NREF_NONE: the medium's own space).  bq_count == 0: any other boundary.
   nref_t bx_inner;
   uint32_t bq_first, bq_count;
-  uint32_t pad;
+  // The boundary holds media itself (constant_medium.rs:19-29 takes any node): each of the reference's `tests` tests of
+  // this medium asks the boundary twice, and every such query makes the media inside draw afresh.  A medium inside such
+  // a boundary owns tests x (2 x the enclosing medium's tests) keys: run c of them serves the enclosing medium's query c.
+  uint32_t nested;
 };
 
 enum : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_DIFFUSE_LIGHT = 3, MK_ISOTROPIC = 4, MK_EMPTY = 5, MK_COUNT = 6 };

@@ -137,9 +137,13 @@ struct Rng {
   uint32_t k0, k1, pixel, stratum, bounce, draw;
   uint32_t cached_block;
   uint32_t c[4];
+  // Which of the enclosing medium's boundary queries is being answered (see the nested form in traverse): a medium met
+  // inside another medium's boundary draws from a run of keys of its own per query, 0 everywhere else.
+  uint32_t mctx;
   __device__ void init(uint32_t seed_lo, uint32_t seed_hi, uint32_t px, uint32_t st, uint32_t b, uint32_t d) {
     k0 = seed_lo; k1 = seed_hi; pixel = px; stratum = st; bounce = b; draw = d;
     cached_block = 0xFFFFFFFFu;
+    mctx = 0;
   }
   __device__ void block(uint32_t blk) {
     uint32_t c0 = pixel, c1 = stratum, c2 = bounce, c3 = blk, a = k0, b = k1;
@@ -765,14 +769,15 @@ template <uint32_t F, bool YIELD, bool CACHE, bool ORD = true>
 __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, TravRay& r, double tmin, double& best_t, nref_t& best, Rng& rng,
                          TravStack& st, const int base, TravCounters& cnt, int yield_below = CHIP_REFILL_THRESH);
 
-// A medium's boundary subtree (constant_medium.rs:42-45) is traversed on the same stack; it may hold
-// anything except another medium.
+// A medium's boundary subtree (constant_medium.rs:42-45) is traversed on the same stack.  It may hold media of its own
+// (constant_medium.rs:19-29 takes any node) as long as theirs are bounded by a sphere or a box, which are queried in
+// place: this instantiation carries the medium code without the sub-traversal, so the nesting ends here.
 template <bool EXT>
 __device__ __noinline__ void traverse_boundary(const DScene& S, nref_t start, TravRay& r, double tmin, double& best_t, nref_t& best,
                                                Rng& rng, TravStack& st, TravCounters& cnt) {
   nref_t node = start;
   NodeCache none{0, 0, 0, 0, 0, 0};
-  traverse<TF_QUADS | TF_XFORM | (EXT ? TF_EXT : 0u), false, false, false>(S, none, node, r, tmin, best_t, best, rng, st, st.sp, cnt);
+  traverse<TF_QUADS | TF_XFORM | TF_MEDIA | TF_MEDIA_BOX | (EXT ? TF_EXT : 0u), false, false, false>(S, none, node, r, tmin, best_t, best, rng, st, st.sp, cnt);
 }
 
 template <uint32_t F, bool YIELD, bool CACHE, bool ORD>
@@ -1013,6 +1018,14 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       const uint32_t outer_mat = r.best_mat;  // the boundary queries below overwrite it
       bool hit_medium = false;
       if (ORD) r.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);  // the boundary queries run the literal form
+      // A medium whose boundary holds media itself: the reference's tests of it (m.tests per world.hit, one after the
+      // other over the shrinking interval) are run one by one here, because each of them asks the boundary twice and
+      // every such query makes the media inside draw afresh; query q of test k is their context 2k + q.  Any other
+      // medium is tested once, with the nearest of its m.tests samples (see below).
+      const bool nested = (F & TF_MEDIA_ANY) && m.nested != 0u;
+      const uint32_t reps = nested ? m.tests : 1u;
+      const uint32_t outer_ctx = rng.mctx;
+      for (uint32_t rep = 0; rep < reps; rep++) {
       double t1 = INFINITY, t2 = INFINITY;
       nref_t b1 = NREF_NONE, b2 = NREF_NONE;
       if ((F & (TF_MEDIA_ANY | TF_MEDIA_BOX)) && m.bq_count != 0u) {
@@ -1057,8 +1070,11 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
           }
         }
       } else if (F & TF_MEDIA_ANY) {
+        if (nested) rng.mctx = 2u * rep;
         traverse_boundary<(F & TF_EXT) != 0>(S, m.boundary, r, -INFINITY, t1, b1, rng, st, cnt);
+        if (nested) rng.mctx = 2u * rep + 1u;
         if (b1 != NREF_NONE) traverse_boundary<(F & TF_EXT) != 0>(S, m.boundary, r, t1 + 0.0001, t2, b2, rng, st, cnt);
+        rng.mctx = outer_ctx;
       }
       if (b1 != NREF_NONE) {
         if (b2 != NREF_NONE) {
@@ -1071,9 +1087,12 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
             // The reference draws one sample per test of the medium and keeps the nearest hit, and it tests a
             // medium more than once per world.hit when the medium is the only object of a BoundingVolumeHierarchy
             // (m.tests).  The nearest of those exponential samples comes from the largest uniform; taking all of
-            // them on every visit makes the visit idempotent and independent of the visiting order.
-            double u = rng.keyed(m.sample_base);
-            for (uint32_t j = 1; j < m.tests; j++) u = fmax(u, rng.keyed(m.sample_base + j));
+            // them on every visit makes the visit idempotent and independent of the visiting order.  (A medium met
+            // inside another's boundary has such a run of keys per query of the enclosing medium: rng.mctx.)
+            const uint32_t key0 = m.sample_base + outer_ctx * m.tests;
+            double u = rng.keyed(nested ? key0 + rep : key0);
+            if (!nested)
+              for (uint32_t j = 1; j < m.tests; j++) u = fmax(u, rng.keyed(key0 + j));
             double hit_distance = m.neg_inv_density * log(u);
             if (!(hit_distance > inside)) {
               best_t = t1 + hit_distance / ray_length;
@@ -1082,6 +1101,7 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
             }
           }
         }
+      }
       }
       r.best_mat = hit_medium ? m.mat : outer_mat;
       if (ORD && hit_medium) r.capf = f32_above(best_t);

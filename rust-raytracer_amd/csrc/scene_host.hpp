@@ -422,6 +422,7 @@ struct HostScene {
     Flat& F;
     uint32_t seq = 0;  // primitives emitted so far, in the reference's depth-first visiting order
     uint64_t medium_samples = 0;  // free-flight sample keys handed out so far (DMedium::sample_base)
+    uint32_t boundary_queries = 0;  // inside a medium's boundary: boundary queries per world.hit of that medium (2 x its tests)
     explicit Flattener(const HostScene& h, Flat& f) : H(h), F(f) {}
 
     void chain_of(nref_t x, std::vector<nref_t>& out) const {
@@ -627,14 +628,21 @@ struct HostScene {
           return self;
         }
         case CHIP_NODE_MEDIUM: {
-          if (in_boundary) throw std::runtime_error("a ConstantMedium inside another medium's boundary is not supported");
           size_t idx = F.media.size();
           F.media.push_back(DMedium{});
-          // keys in depth-first order of the expanded graph: a medium node reached along two ways is two media
+          // keys in depth-first order of the expanded graph: a medium node reached along two ways is two media.  A medium
+          // inside another medium's boundary (boundary_queries != 0: how many boundary queries one world.hit makes of the
+          // enclosing medium, two per test) owns a run of `tests` keys per such query.
+          const bool inside_boundary = in_boundary;
           const uint32_t sample_base = (uint32_t)medium_samples;
-          medium_samples += tests;
+          medium_samples += (uint64_t)tests * (inside_boundary ? boundary_queries : 1u);
           if (medium_samples >= (1ull << 31)) throw std::runtime_error("too many ConstantMedium samples per ray segment (2^31 at most)");
+          const uint32_t outer_queries = boundary_queries;
+          boundary_queries = 2u * tests;
           nref_t b = emit(n.c0, xform, true, -1);
+          boundary_queries = outer_queries;
+          const bool nested = F.media.size() > idx + 1;  // the boundary brought media of its own
+          if (nested && inside_boundary) throw std::runtime_error("a ConstantMedium whose boundary holds media, inside another medium's boundary, is not supported (one level of nesting)");
           DMedium& m = F.media[idx];
           m.neg_inv_density = n.a[0];
           m.boundary = b;
@@ -646,7 +654,7 @@ struct HostScene {
           // the common boundary besides a sphere: a box, possibly inside instances that hold nothing else
           m.bx_inner = NREF_NONE;
           m.bq_first = m.bq_count = 0;
-          m.pad = 0;
+          m.nested = nested ? 1u : 0u;
           {
             nref_t inner = NREF_NONE, c = b;
             for (int guard = 0; guard < 64; guard++) {
@@ -663,6 +671,10 @@ struct HostScene {
               if (quads_only) { m.bx_inner = inner; m.bq_first = g.first; m.bq_count = g.count; }
             }
           }
+          // the boundary queries of a medium inside a boundary are answered in place (the traversal of a boundary carries
+          // no sub-traversal of its own)
+          if (inside_boundary && m.bq_count == 0 && NREF_KIND(b) != NK_SPHERE)
+            throw std::runtime_error("a ConstantMedium inside another medium's boundary must itself be bounded by a sphere or a box");
           return NREF(NK_MEDIUM, idx);
         }
       }
