@@ -11,7 +11,7 @@ import pytest
 from helpers import compare_hits
 
 SEEDS = list(range(12))
-VARIANT = int(os.environ.get("CHIP_TEST_GRAPH_VARIANT", "0"))  # 1: discs with any normal, media bounded by turned boxes (sweeps only)
+VARIANT = int(os.environ.get("CHIP_TEST_GRAPH_VARIANT", "0"))  # (sweeps only) 1: discs with any normal, media bounded by turned boxes; 2: media whose boundaries hold media
 if os.environ.get("CHIP_TEST_GRAPH_SEEDS"):  # "FIRST:LAST" (inclusive): other seeds, for tools/fish_random_graphs.py
     _first, _last = (int(x) for x in os.environ["CHIP_TEST_GRAPH_SEEDS"].split(":"))
     SEEDS = list(range(_first, _last + 1))
@@ -73,6 +73,19 @@ def random_graph(sc, seed, with_media=True, with_lights=False):
             elif k == 9 and with_media and VARIANT == 1:
                 shell = sc.translate(sc.rotate(sc.box((0, 0, 0), tuple(float(x) for x in rng.uniform(0.8, 2.5, 3)), mats[0]), (0, 1, 0), float(rng.uniform(-90, 90))), point(5.0))
                 n = sc.constant_medium_color(shell, float(rng.uniform(0.1, 1.5)), 0.9, 0.9, 0.9)
+            elif k == 9 and with_media and VARIANT == 2:
+                # a medium whose boundary holds a medium of its own (sphere- or box-bounded, now and then alone in a hierarchy)
+                c = np.array(point())
+                if rng.random() < 0.5:
+                    inner_b = sc.sphere(tuple(map(float, c + rng.uniform(-0.6, 0.6, 3))), float(rng.uniform(0.4, 1.0)), mats[0])
+                else:
+                    inner_b = sc.translate(sc.rotate(sc.box((0, 0, 0), tuple(float(x) for x in rng.uniform(0.5, 1.4, 3)), mats[0]), (0, 1, 0), float(rng.uniform(-90, 90))),
+                                           tuple(map(float, c + rng.uniform(-0.8, 0.2, 3))))
+                inner = sc.constant_medium_color(inner_b, float(rng.uniform(0.3, 2.5)), 0.9, 0.9, 0.9)
+                if rng.random() < 0.3:
+                    inner = sc.bvh([inner])
+                n = sc.constant_medium_color(sc.group([sc.sphere(tuple(map(float, c)), float(rng.uniform(1.0, 2.2)), mats[0]), inner]), float(rng.uniform(0.1, 1.5)),
+                                             0.9, 0.9, 0.9)
             elif k == 9 and with_media:
                 n = sc.constant_medium_color(sc.sphere(point(), float(rng.uniform(0.8, 2.0)), mats[0]), float(rng.uniform(0.1, 1.5)), 0.9, 0.9, 0.9)
             else:
