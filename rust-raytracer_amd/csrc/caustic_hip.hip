@@ -666,6 +666,21 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   for (const DTexture& t : s->host.textures) plain_textures = plain_textures && (t.kind == TK_SOLID || t.kind == TK_CHECKER);
   const bool fused_first_ok = fused_first_possible(xplans, lean);
   const bool lean_xform = solid_only && (feat & ~TF_NO_QUADROT) == (TF_QUADS | TF_XFORM) && s->flat.quads.empty() && s->flat.media.empty();
+  // scenes of a few primitives, materials and lights (no discs, cones or Scale): the shade kernel works from LDS copies of
+  // the record tables (CHIP_NO_SHADE_TABLES=1 keeps them in memory: tests compare the two)
+  ShadeTables shade_tbl{};
+  bool shade_tbl_ok = false;
+  if (!lean && !lean_xform && plain_textures && !(feat & TF_EXT)) {
+    const Flat& F = s->flat;
+    shade_tbl = ShadeTables{(uint32_t)F.spheres.size(), (uint32_t)F.quads.size(), (uint32_t)F.translates.size(), (uint32_t)F.rotates.size(),
+                            (uint32_t)F.xchain.size(), (uint32_t)F.media.size(), (uint32_t)s->host.materials.size(), (uint32_t)s->host.textures.size(),
+                            (uint32_t)F.lights.size(), (uint32_t)F.ltree.size()};
+    const size_t records = F.spheres.size() + F.quads.size() + F.translates.size() + F.rotates.size() + F.xchain.size() + F.media.size() +
+                           s->host.materials.size() + s->host.textures.size() + F.lights.size() + F.ltree.size();
+    uint32_t off[10];
+    const char* e = getenv("CHIP_NO_SHADE_TABLES");
+    shade_tbl_ok = records < 4096 && shade_tables_layout(shade_tbl, off) <= CHIP_SHADE_TBL_BYTES && !(e && *e == '1');
+  }
 
   // pools: two when the render is large enough to be worth splitting
   int n_lanes = 1;
@@ -828,20 +843,28 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
         const bool ext = (feat & TF_EXT) != 0;
 #define CHIP_SHADE(FAST, LEAN, EXT, PASS)                                                                                          \
   do {                                                                                                                         \
-    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
-    else hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT, false>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
+    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS, ShadeTables{}); \
+    else hipLaunchKernelGGL((k_shade_tiles<FAST, LEAN, EXT, false>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS, ShadeTables{}); \
   } while (0)
         // the full kernel's form without image / noise texture code: everything (SHADE_ALL) when the scene has no such
         // texture, else everything but the hits on materials that have one, which a second launch of the full kernel takes
 #define CHIP_SHADE_PLAIN(FAST, EXT, PASS)                                                                                         \
   do {                                                                                                                         \
-    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, false, EXT, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
-    else hipLaunchKernelGGL((k_shade_tiles<FAST, false, EXT, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS); \
+    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, false, EXT, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS, ShadeTables{}); \
+    else hipLaunchKernelGGL((k_shade_tiles<FAST, false, EXT, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS, ShadeTables{}); \
+  } while (0)
+        // the same with the scene's record tables copied into LDS (scenes of a few primitives, materials and lights)
+#define CHIP_SHADE_PLAIN_TBL(FAST, PASS)                                                                                          \
+  do {                                                                                                                         \
+    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, false, false, true, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS, shade_tbl); \
+    else hipLaunchKernelGGL((k_shade_tiles<FAST, false, false, false, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS, shade_tbl); \
   } while (0)
         if (lean) {
           if (exact_shading) CHIP_SHADE(false, true, false, shade_pass_all); else CHIP_SHADE(true, true, false, shade_pass_all);
         } else if (lean_xform) {
           if (exact_shading) CHIP_SHADE(false, true, true, SHADE_ALL); else CHIP_SHADE(true, true, true, SHADE_ALL);
+        } else if (plain_textures && shade_tbl_ok) {
+          if (exact_shading) CHIP_SHADE_PLAIN_TBL(false, SHADE_ALL); else CHIP_SHADE_PLAIN_TBL(true, SHADE_ALL);
         } else if (plain_textures) {
           if (ext) { if (exact_shading) CHIP_SHADE_PLAIN(false, true, SHADE_ALL); else CHIP_SHADE_PLAIN(true, true, SHADE_ALL); }
           else { if (exact_shading) CHIP_SHADE_PLAIN(false, false, SHADE_ALL); else CHIP_SHADE_PLAIN(true, false, SHADE_ALL); }
@@ -852,6 +875,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
           if (exact_shading) CHIP_SHADE_PLAIN(false, false, SHADE_PLAIN_ONLY); else CHIP_SHADE_PLAIN(true, false, SHADE_PLAIN_ONLY);
           if (exact_shading) CHIP_SHADE(false, false, false, SHADE_RICH_ONLY); else CHIP_SHADE(true, false, false, SHADE_RICH_ONLY);
         }
+#undef CHIP_SHADE_PLAIN_TBL
 #undef CHIP_SHADE_PLAIN
 #undef CHIP_SHADE
       }

@@ -2516,9 +2516,60 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
 // in which the traversal kernel shades its own hits (k_first_small) and only the rays it handed to the literal pass are
 // left.
 enum : uint32_t { SHADE_ALL = 0, SHADE_PLAIN_ONLY = 1, SHADE_RICH_ONLY = 2, SHADE_LIT_QUEUE = 3 };
-template <bool FAST, bool LEAN, bool EXT, bool B0, bool PLAIN = false>
-__global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_WAVES : (LEAN ? 1 : (PLAIN ? CHIP_SHADE_PLAIN_WAVES : CHIP_SHADE_FULL_WAVES))) k_shade_tiles(DScene S, PathPool P, BatchDesc B, uint32_t bounce_arg, uint32_t pass) {
+// TBL: the scene's record tables are small enough to sit in LDS (a Cornell box: 13 primitives, 6 materials, 2 lights).
+// Shading a hit follows a chain of dependent reads (hit -> primitive -> its transforms -> material -> texture -> light list
+// -> light's primitive), each a trip to L2 when the tables are in memory; a block of this form copies them into LDS
+// first and shades from a DScene whose table pointers name the copies, so every link of the chain is an LDS read.
+#define CHIP_SHADE_TBL_BYTES 12288u
+struct ShadeTables {  // records per table (the host checked that they fit CHIP_SHADE_TBL_BYTES, see shade_tables_fit)
+  uint32_t n_spheres, n_quads, n_translates, n_rotates, n_xchain, n_media, n_materials, n_textures, n_lights, n_ltree;
+};
+__host__ __device__ inline uint32_t tbl_up(uint32_t v, uint32_t a) { return (v + a - 1u) & ~(a - 1u); }
+// byte offsets of the tables inside the LDS copy, each at its record type's alignment; returns the total
+__host__ __device__ inline uint32_t shade_tables_layout(const ShadeTables& n, uint32_t (&off)[10]) {
+  uint32_t at = 0;
+  off[0] = at = tbl_up(at, alignof(DSphere)); at += n.n_spheres * (uint32_t)sizeof(DSphere);
+  off[1] = at = tbl_up(at, alignof(DTranslate)); at += n.n_translates * (uint32_t)sizeof(DTranslate);
+  off[2] = at = tbl_up(at, 16u); at += n.n_quads * (uint32_t)sizeof(DQuad);
+  off[3] = at = tbl_up(at, 16u); at += n.n_rotates * (uint32_t)sizeof(DRotate);
+  off[4] = at = tbl_up(at, 16u); at += n.n_media * (uint32_t)sizeof(DMedium);
+  off[5] = at = tbl_up(at, 16u); at += n.n_materials * (uint32_t)sizeof(DMaterial);
+  off[6] = at = tbl_up(at, 16u); at += n.n_textures * (uint32_t)sizeof(DTexture);
+  off[7] = at = tbl_up(at, 16u); at += n.n_lights * (uint32_t)sizeof(DLight);
+  off[8] = at = tbl_up(at, 16u); at += n.n_ltree * (uint32_t)sizeof(DLightNode);
+  off[9] = at = tbl_up(at, 16u); at += n.n_xchain * (uint32_t)sizeof(nref_t);
+  return tbl_up(at, 16u);
+}
+template <typename T>
+__device__ inline const T* shade_table_copy(unsigned char* lds, uint32_t off, const T* src, uint32_t n) {
+  static_assert(sizeof(T) % 4 == 0, "tables are copied word by word");
+  const uint32_t words = n * (uint32_t)(sizeof(T) / 4);
+  uint32_t* d = reinterpret_cast<uint32_t*>(lds + off);
+  const uint32_t* g = reinterpret_cast<const uint32_t*>(src);
+  for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) d[i] = g[i];
+  return reinterpret_cast<const T*>(lds + off);
+}
+template <bool FAST, bool LEAN, bool EXT, bool B0, bool PLAIN = false, bool TBL = false>
+__global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_WAVES : (LEAN ? 1 : (PLAIN ? CHIP_SHADE_PLAIN_WAVES : CHIP_SHADE_FULL_WAVES))) k_shade_tiles(DScene S_arg, PathPool P, BatchDesc B, uint32_t bounce_arg, uint32_t pass, ShadeTables tbl) {
   const uint32_t bounce = B0 ? 0u : bounce_arg;
+  __shared__ __attribute__((aligned(128))) unsigned char s_tbl[TBL ? CHIP_SHADE_TBL_BYTES : 16];
+  DScene S_lds = S_arg;
+  if (TBL) {
+    uint32_t off[10];
+    shade_tables_layout(tbl, off);
+    S_lds.spheres = shade_table_copy(s_tbl, off[0], S_arg.spheres, tbl.n_spheres);
+    S_lds.translates = shade_table_copy(s_tbl, off[1], S_arg.translates, tbl.n_translates);
+    S_lds.quads = shade_table_copy(s_tbl, off[2], S_arg.quads, tbl.n_quads);
+    S_lds.rotates = shade_table_copy(s_tbl, off[3], S_arg.rotates, tbl.n_rotates);
+    S_lds.media = shade_table_copy(s_tbl, off[4], S_arg.media, tbl.n_media);
+    S_lds.materials = shade_table_copy(s_tbl, off[5], S_arg.materials, tbl.n_materials);
+    S_lds.textures = shade_table_copy(s_tbl, off[6], S_arg.textures, tbl.n_textures);
+    S_lds.lights = shade_table_copy(s_tbl, off[7], S_arg.lights, tbl.n_lights);
+    S_lds.ltree = shade_table_copy(s_tbl, off[8], S_arg.ltree, tbl.n_ltree);
+    S_lds.xchain = shade_table_copy(s_tbl, off[9], S_arg.xchain, tbl.n_xchain);
+    __syncthreads();
+  }
+  const DScene& S = TBL ? S_lds : S_arg;
 #if CHIP_SHADE_PRIO
   __builtin_amdgcn_s_setprio(CHIP_SHADE_PRIO);
 #endif

@@ -913,6 +913,35 @@ def test_flat_form_equals_the_hierarchy_walk(pkg, gpu, oracle, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_shading_from_lds_tables_equals_shading_from_memory(pkg, gpu, oracle, monkeypatch):
+    """A scene of a few primitives, materials and lights with plain textures (the Cornell boxes, the quads scene, spheres
+    under a light, checkered spheres) is shaded from copies of its record tables in LDS; CHIP_NO_SHADE_TABLES=1 leaves
+    them in memory.  Same records, same arithmetic: the frames are the same bits in both shading modes, at bounce 0 and
+    later; a scene whose tables do not fit (the Next-Week scene) takes the other kernel either way."""
+    monkeypatch.delenv("CHIP_NO_SHADE_TABLES", raising=False)
+    X = pkg.bindings.RENDER_EXACT_SHADING
+    for name, kw, seed in (("cornell_box", dict(width=120, spp=16, depth=12), 3), ("cornell_box_smoke", dict(width=120, spp=16, depth=12), 5),
+                           ("quads", dict(width=120, spp=9, depth=8), 2), ("lighted_sphere", dict(width=120, spp=9, depth=8), 4),
+                           ("checkered_spheres", dict(width=120, spp=9, depth=8), 6), ("final", dict(width=96, spp=4, depth=8), 1)):
+        sc = pkg.scenes.build(gpu, name, **kw)
+        for flags in (0, X, X | pkg.bindings.RENDER_REFERENCE_ORDER):
+            lds, _, st1 = sc.render_frame(seed=seed, flags=flags)
+            monkeypatch.setenv("CHIP_NO_SHADE_TABLES", "1")
+            mem, _, st2 = sc.render_frame(seed=seed, flags=flags)
+            monkeypatch.delenv("CHIP_NO_SHADE_TABLES")
+            assert st1["segments"] == st2["segments"] and st1["paths"] == st2["paths"], (name, kw, flags)
+            assert np.array_equal(lds.view(np.uint32), mem.view(np.uint32)), (name, kw, flags)
+    for name in ("cornell_box", "cornell_box_smoke"):
+        so = pkg.scenes.build(oracle, name, width=64, spp=4, depth=10)
+        sg = pkg.scenes.build(gpu, name, width=64, spp=4, depth=10)
+        img_o, _, st_o = so.render_frame(seed=7, sum_dtype=np.float64)
+        img_g, _, st_g = sg.render_frame(seed=7, flags=X)
+        assert st_g["segments"] == st_o["segments"]
+        diff = np.abs(img_g.astype(np.float64) - img_o)
+        assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
+
+
+@pytest.mark.gpu
 def test_literal_hand_over_of_every_fifth_ray(pkg, gpu):
     """The ordered traversal hands a ray it cannot take (a zero direction component, a descent deeper than the compact
     form's stack) to the literal traversal, which runs as a pass of its own after it: a ray or two per frame in the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Renders every scene of scenes.py once at a small size and prints throughput and the traversal / shading split:
-a sweep that shows which kernel variants a scene runs at what speed.  usage: run_all_scenes.py [width] [spp]"""
+a sweep that shows which kernel variants a scene runs at what speed.  usage: run_all_scenes.py [width] [spp] [scene ...]"""
 import importlib, json, os, sys, time
 import torch  # noqa: F401
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ pkg = importlib.import_module("rust-raytracer_amd")
 gpu = pkg.load_gpu()
 width = int(sys.argv[1]) if len(sys.argv) > 1 else 800
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-for name in pkg.scenes.SCENES:
+for name in (sys.argv[3:] or pkg.scenes.SCENES):
     try:
         sc = pkg.scenes.build(gpu, name, width=width, spp=spp, depth=50)
         sc.render_frame(seed=1)
