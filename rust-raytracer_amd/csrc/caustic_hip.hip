@@ -666,18 +666,19 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   for (const DTexture& t : s->host.textures) plain_textures = plain_textures && (t.kind == TK_SOLID || t.kind == TK_CHECKER);
   const bool fused_first_ok = fused_first_possible(xplans, lean);
   const bool lean_xform = solid_only && (feat & ~TF_NO_QUADROT) == (TF_QUADS | TF_XFORM) && s->flat.quads.empty() && s->flat.media.empty();
-  // scenes of a few primitives, materials and lights (no discs, cones or Scale): the shade kernel works from LDS copies of
-  // the record tables (CHIP_NO_SHADE_TABLES=1 keeps them in memory: tests compare the two)
+  // scenes of a few primitives, materials and lights: the shade kernel works from LDS copies of the record tables
+  // (CHIP_NO_SHADE_TABLES=1 keeps them in memory: tests compare the two)
   ShadeTables shade_tbl{};
   bool shade_tbl_ok = false;
-  if (!lean && !lean_xform && plain_textures && !(feat & TF_EXT)) {
+  if (!lean && !lean_xform && plain_textures) {
     const Flat& F = s->flat;
     shade_tbl = ShadeTables{(uint32_t)F.spheres.size(), (uint32_t)F.quads.size(), (uint32_t)F.translates.size(), (uint32_t)F.rotates.size(),
                             (uint32_t)F.xchain.size(), (uint32_t)F.media.size(), (uint32_t)s->host.materials.size(), (uint32_t)s->host.textures.size(),
-                            (uint32_t)F.lights.size(), (uint32_t)F.ltree.size()};
+                            (uint32_t)F.lights.size(), (uint32_t)F.ltree.size(), (uint32_t)F.discs.size(), (uint32_t)F.cones.size(), (uint32_t)F.scales.size()};
     const size_t records = F.spheres.size() + F.quads.size() + F.translates.size() + F.rotates.size() + F.xchain.size() + F.media.size() +
-                           s->host.materials.size() + s->host.textures.size() + F.lights.size() + F.ltree.size();
-    uint32_t off[10];
+                           s->host.materials.size() + s->host.textures.size() + F.lights.size() + F.ltree.size() + F.discs.size() + F.cones.size() +
+                           F.scales.size();
+    uint32_t off[13];
     const char* e = getenv("CHIP_NO_SHADE_TABLES");
     shade_tbl_ok = records < 4096 && shade_tables_layout(shade_tbl, off) <= CHIP_SHADE_TBL_BYTES && !(e && *e == '1');
   }
@@ -854,17 +855,18 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
     else hipLaunchKernelGGL((k_shade_tiles<FAST, false, EXT, false, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS, ShadeTables{}); \
   } while (0)
         // the same with the scene's record tables copied into LDS (scenes of a few primitives, materials and lights)
-#define CHIP_SHADE_PLAIN_TBL(FAST, PASS)                                                                                          \
+#define CHIP_SHADE_PLAIN_TBL(FAST, EXT, PASS)                                                                                     \
   do {                                                                                                                         \
-    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, false, false, true, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS, shade_tbl); \
-    else hipLaunchKernelGGL((k_shade_tiles<FAST, false, false, false, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS, shade_tbl); \
+    if (bounce == 0) hipLaunchKernelGGL((k_shade_tiles<FAST, false, EXT, true, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS, shade_tbl); \
+    else hipLaunchKernelGGL((k_shade_tiles<FAST, false, EXT, false, true, true>), dim3(grid), dim3(CHIP_BLOCK), 0, L.st, S, P, B, bounce, PASS, shade_tbl); \
   } while (0)
         if (lean) {
           if (exact_shading) CHIP_SHADE(false, true, false, shade_pass_all); else CHIP_SHADE(true, true, false, shade_pass_all);
         } else if (lean_xform) {
           if (exact_shading) CHIP_SHADE(false, true, true, SHADE_ALL); else CHIP_SHADE(true, true, true, SHADE_ALL);
         } else if (plain_textures && shade_tbl_ok) {
-          if (exact_shading) CHIP_SHADE_PLAIN_TBL(false, SHADE_ALL); else CHIP_SHADE_PLAIN_TBL(true, SHADE_ALL);
+          if (ext) { if (exact_shading) CHIP_SHADE_PLAIN_TBL(false, true, SHADE_ALL); else CHIP_SHADE_PLAIN_TBL(true, true, SHADE_ALL); }
+          else { if (exact_shading) CHIP_SHADE_PLAIN_TBL(false, false, SHADE_ALL); else CHIP_SHADE_PLAIN_TBL(true, false, SHADE_ALL); }
         } else if (plain_textures) {
           if (ext) { if (exact_shading) CHIP_SHADE_PLAIN(false, true, SHADE_ALL); else CHIP_SHADE_PLAIN(true, true, SHADE_ALL); }
           else { if (exact_shading) CHIP_SHADE_PLAIN(false, false, SHADE_ALL); else CHIP_SHADE_PLAIN(true, false, SHADE_ALL); }

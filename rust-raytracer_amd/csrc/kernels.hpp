@@ -2523,10 +2523,11 @@ enum : uint32_t { SHADE_ALL = 0, SHADE_PLAIN_ONLY = 1, SHADE_RICH_ONLY = 2, SHAD
 #define CHIP_SHADE_TBL_BYTES 12288u
 struct ShadeTables {  // records per table (the host checked that they fit CHIP_SHADE_TBL_BYTES, see shade_tables_fit)
   uint32_t n_spheres, n_quads, n_translates, n_rotates, n_xchain, n_media, n_materials, n_textures, n_lights, n_ltree;
+  uint32_t n_discs, n_cones, n_scales;  // (scenes with these run the EXT instantiation)
 };
 __host__ __device__ inline uint32_t tbl_up(uint32_t v, uint32_t a) { return (v + a - 1u) & ~(a - 1u); }
 // byte offsets of the tables inside the LDS copy, each at its record type's alignment; returns the total
-__host__ __device__ inline uint32_t shade_tables_layout(const ShadeTables& n, uint32_t (&off)[10]) {
+__host__ __device__ inline uint32_t shade_tables_layout(const ShadeTables& n, uint32_t (&off)[13]) {
   uint32_t at = 0;
   off[0] = at = tbl_up(at, alignof(DSphere)); at += n.n_spheres * (uint32_t)sizeof(DSphere);
   off[1] = at = tbl_up(at, alignof(DTranslate)); at += n.n_translates * (uint32_t)sizeof(DTranslate);
@@ -2538,6 +2539,9 @@ __host__ __device__ inline uint32_t shade_tables_layout(const ShadeTables& n, ui
   off[7] = at = tbl_up(at, 16u); at += n.n_lights * (uint32_t)sizeof(DLight);
   off[8] = at = tbl_up(at, 16u); at += n.n_ltree * (uint32_t)sizeof(DLightNode);
   off[9] = at = tbl_up(at, 16u); at += n.n_xchain * (uint32_t)sizeof(nref_t);
+  off[10] = at = tbl_up(at, 16u); at += n.n_discs * (uint32_t)sizeof(DDisc);
+  off[11] = at = tbl_up(at, 16u); at += n.n_cones * (uint32_t)sizeof(DCone);
+  off[12] = at = tbl_up(at, 16u); at += n.n_scales * (uint32_t)sizeof(DScale);
   return tbl_up(at, 16u);
 }
 template <typename T>
@@ -2555,7 +2559,7 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
   __shared__ __attribute__((aligned(128))) unsigned char s_tbl[TBL ? CHIP_SHADE_TBL_BYTES : 16];
   DScene S_lds = S_arg;
   if (TBL) {
-    uint32_t off[10];
+    uint32_t off[13];
     shade_tables_layout(tbl, off);
     S_lds.spheres = shade_table_copy(s_tbl, off[0], S_arg.spheres, tbl.n_spheres);
     S_lds.translates = shade_table_copy(s_tbl, off[1], S_arg.translates, tbl.n_translates);
@@ -2567,6 +2571,11 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
     S_lds.lights = shade_table_copy(s_tbl, off[7], S_arg.lights, tbl.n_lights);
     S_lds.ltree = shade_table_copy(s_tbl, off[8], S_arg.ltree, tbl.n_ltree);
     S_lds.xchain = shade_table_copy(s_tbl, off[9], S_arg.xchain, tbl.n_xchain);
+    if (EXT) {
+      S_lds.discs = shade_table_copy(s_tbl, off[10], S_arg.discs, tbl.n_discs);
+      S_lds.cones = shade_table_copy(s_tbl, off[11], S_arg.cones, tbl.n_cones);
+      S_lds.scales = shade_table_copy(s_tbl, off[12], S_arg.scales, tbl.n_scales);
+    }
     __syncthreads();
   }
   const DScene& S = TBL ? S_lds : S_arg;

@@ -915,14 +915,16 @@ def test_flat_form_equals_the_hierarchy_walk(pkg, gpu, oracle, monkeypatch):
 @pytest.mark.gpu
 def test_shading_from_lds_tables_equals_shading_from_memory(pkg, gpu, oracle, monkeypatch):
     """A scene of a few primitives, materials and lights with plain textures (the Cornell boxes, the quads scene, spheres
-    under a light, checkered spheres) is shaded from copies of its record tables in LDS; CHIP_NO_SHADE_TABLES=1 leaves
+    under a light, checkered spheres, OpenSCAD-shaped scenes with discs, cone frusta and Scale) is shaded from copies of its record tables in LDS; CHIP_NO_SHADE_TABLES=1 leaves
     them in memory.  Same records, same arithmetic: the frames are the same bits in both shading modes, at bounce 0 and
     later; a scene whose tables do not fit (the Next-Week scene) takes the other kernel either way."""
     monkeypatch.delenv("CHIP_NO_SHADE_TABLES", raising=False)
     X = pkg.bindings.RENDER_EXACT_SHADING
     for name, kw, seed in (("cornell_box", dict(width=120, spp=16, depth=12), 3), ("cornell_box_smoke", dict(width=120, spp=16, depth=12), 5),
                            ("quads", dict(width=120, spp=9, depth=8), 2), ("lighted_sphere", dict(width=120, spp=9, depth=8), 4),
-                           ("checkered_spheres", dict(width=120, spp=9, depth=8), 6), ("final", dict(width=96, spp=4, depth=8), 1)):
+                           ("checkered_spheres", dict(width=120, spp=9, depth=8), 6), ("final", dict(width=96, spp=4, depth=8), 1),
+                           ("scad_shapes", dict(width=120, spp=9, depth=8), 7), ("lighted_cone_frustum", dict(width=120, spp=9, depth=8), 8),
+                           ("scad_shapes_cone_light", dict(width=120, spp=9, depth=8), 9)):
         sc = pkg.scenes.build(gpu, name, **kw)
         for flags in (0, X, X | pkg.bindings.RENDER_REFERENCE_ORDER):
             lds, _, st1 = sc.render_frame(seed=seed, flags=flags)
