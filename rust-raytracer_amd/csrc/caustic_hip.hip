@@ -664,6 +664,8 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   // solid colours and checkers only: the full shade kernel without its image / noise texture code
   bool plain_textures = true;
   for (const DTexture& t : s->host.textures) plain_textures = plain_textures && (t.kind == TK_SOLID || t.kind == TK_CHECKER);
+  bool all_rich = !s->host.materials.empty();
+  for (const DMaterial& m : s->host.materials) all_rich = all_rich && (m.flags & MF_RICH_TEX) != 0;
   const bool fused_first_ok = fused_first_possible(xplans, lean);
   const bool lean_xform = solid_only && (feat & ~TF_NO_QUADROT) == (TF_QUADS | TF_XFORM) && s->flat.quads.empty() && s->flat.media.empty();
   // scenes of a few primitives, materials and lights: the shade kernel works from LDS copies of the record tables
@@ -870,12 +872,20 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
         } else if (plain_textures) {
           if (ext) { if (exact_shading) CHIP_SHADE_PLAIN(false, true, SHADE_ALL); else CHIP_SHADE_PLAIN(true, true, SHADE_ALL); }
           else { if (exact_shading) CHIP_SHADE_PLAIN(false, false, SHADE_ALL); else CHIP_SHADE_PLAIN(true, false, SHADE_ALL); }
+        } else if (all_rich) {  // every material carries an image / noise texture: the full kernel takes the whole bounce
+          if (ext) { if (exact_shading) CHIP_SHADE(false, false, true, SHADE_ALL); else CHIP_SHADE(true, false, true, SHADE_ALL); }
+          else { if (exact_shading) CHIP_SHADE(false, false, false, SHADE_ALL); else CHIP_SHADE(true, false, false, SHADE_ALL); }
         } else if (ext) {
           if (exact_shading) CHIP_SHADE_PLAIN(false, true, SHADE_PLAIN_ONLY); else CHIP_SHADE_PLAIN(true, true, SHADE_PLAIN_ONLY);
-          if (exact_shading) CHIP_SHADE(false, false, true, SHADE_RICH_ONLY); else CHIP_SHADE(true, false, true, SHADE_RICH_ONLY);
+          // (the second pass goes over the hits the first one listed for it: a fraction of the bounce, and a grid to match)
+          const uint32_t grid_all = grid;
+          { const uint32_t grid = std::max(1u, grid_all / 4u);
+            if (exact_shading) CHIP_SHADE(false, false, true, SHADE_RICH_ONLY); else CHIP_SHADE(true, false, true, SHADE_RICH_ONLY); }
         } else {
           if (exact_shading) CHIP_SHADE_PLAIN(false, false, SHADE_PLAIN_ONLY); else CHIP_SHADE_PLAIN(true, false, SHADE_PLAIN_ONLY);
-          if (exact_shading) CHIP_SHADE(false, false, false, SHADE_RICH_ONLY); else CHIP_SHADE(true, false, false, SHADE_RICH_ONLY);
+          const uint32_t grid_all = grid;
+          { const uint32_t grid = std::max(1u, grid_all / 4u);
+            if (exact_shading) CHIP_SHADE(false, false, false, SHADE_RICH_ONLY); else CHIP_SHADE(true, false, false, SHADE_RICH_ONLY); }
         }
 #undef CHIP_SHADE_PLAIN_TBL
 #undef CHIP_SHADE_PLAIN

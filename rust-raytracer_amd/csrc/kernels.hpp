@@ -61,6 +61,7 @@
 #define CHIP_CTR_CURSOR 7
 #define CHIP_CTR_LIT 8
 #define CHIP_CTR_LIT_CURSOR 9
+#define CHIP_CTR_RICH 10  // entries the plain-texture shade pass left to the pass with the image / noise texture code
 
 // ------------------------------------------------------------------ path pool
 // The live paths of a bounce are kept dense: entry i of a bounce is one small record per consumer
@@ -2587,14 +2588,18 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
   PathMap* st_out = P.st[(bounce + 1) & 1];
   uint32_t* ctr = P.counters + (size_t)bounce * CHIP_CTR_STRIDE;
   uint32_t* ctr_next = P.counters + (size_t)(bounce + 1) * CHIP_CTR_STRIDE;
-  const bool via_queue = B0 && pass == SHADE_LIT_QUEUE;  // entry i of this launch is q_lit[i]
-  const uint32_t n_live = via_queue ? ctr[CHIP_CTR_LIT] : ctr[0];
+  // entry i of this launch is q_lit[i]: the rays the fused first bounce left to the literal pass, or the hits the
+  // plain-texture pass left to this one (it lists them in the queue, which the traversal is done with by then, so that
+  // this pass goes over those few entries instead of the whole bounce)
+  const bool rich_queue = !LEAN && pass == SHADE_RICH_ONLY;
+  const bool via_queue = (B0 && pass == SHADE_LIT_QUEUE) || rich_queue;
+  const uint32_t n_live = rich_queue ? ctr[CHIP_CTR_RICH] : (via_queue ? ctr[CHIP_CTR_LIT] : ctr[0]);
   const bool last_bounce = bounce + 1 >= S.cam.max_depth;
   constexpr uint32_t NB = MK_COUNT + 3;        // material kinds, misses, empty entries, entries left to the other pass
   __shared__ uint16_t s_order[CHIP_SHADE_TILE];  // tile-local entry numbers, sorted by bin
   __shared__ uint16_t s_rank[CHIP_SHADE_TILE];
   __shared__ uint8_t s_kind[CHIP_SHADE_TILE];
-  __shared__ uint32_t s_cnt[NB], s_off[NB + 1], s_live, s_base, s_reserved;
+  __shared__ uint32_t s_cnt[NB], s_off[NB + 1], s_live, s_base, s_reserved, s_qbase;
   __shared__ uint4 s_stage[CHIP_BLOCK / 64][CHIP_XPOSE_U4];
   uint4* stage = s_stage[threadIdx.x >> 6];
   // entries per tile: up to CHIP_SHADE_TILE, but small enough that a short queue still spreads over the grid
@@ -2611,11 +2616,11 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
       const uint32_t e = via_queue ? P.q_lit[tile0 + k] : tile0 + k;
       const uint2 hw = *reinterpret_cast<const uint2*>(&P.hit[e].node);
       uint32_t kind = hw.x == NREF_NONE ? MK_COUNT : (hw.x == NREF_DEAD ? MK_COUNT + 1 : MATK_KIND(hw.y));
-      if (pass == SHADE_PLAIN_ONLY || pass == SHADE_RICH_ONLY) {
+      if (!LEAN && pass == SHADE_PLAIN_ONLY) {
         // two launches share the bounce: hits on materials with an image / noise texture go to the second one (the
-        // full kernel), everything else, misses included, to the first (the kernel without that code)
+        // full kernel), everything else, misses included, to this one (the kernel without that code)
         const bool rich = kind < MK_COUNT && (S.materials[MATK_ID(hw.y)].flags & MF_RICH_TEX) != 0;
-        if (rich != (pass == SHADE_RICH_ONLY)) kind = MK_COUNT + 2;
+        if (rich) kind = MK_COUNT + 2;
       }
       s_kind[k] = (uint8_t)kind;
       s_rank[k] = (uint16_t)atomicAdd(&s_cnt[kind], 1u);
@@ -2629,10 +2634,13 @@ __global__ void __launch_bounds__(CHIP_BLOCK, (LEAN && FAST) ? CHIP_SHADE_LEAN_W
       const uint32_t reserve = last_bounce ? 0u : s_cnt[MK_LAMBERTIAN] + s_cnt[MK_METAL] + s_cnt[MK_DIELECTRIC] + s_cnt[MK_ISOTROPIC];
       s_reserved = reserve;
       s_base = reserve ? atomicAdd(&ctr_next[0], reserve) : 0u;
+      s_qbase = (!LEAN && pass == SHADE_PLAIN_ONLY && s_cnt[NB - 1]) ? atomicAdd(&ctr[CHIP_CTR_RICH], s_cnt[NB - 1]) : 0u;
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < tile_n; k += CHIP_BLOCK) s_order[s_off[s_kind[k]] + s_rank[k]] = (uint16_t)k;
     __syncthreads();
+    if (!LEAN && pass == SHADE_PLAIN_ONLY)  // the entries left to the other pass, listed for it
+      for (uint32_t i = threadIdx.x; i < s_cnt[NB - 1]; i += CHIP_BLOCK) P.q_lit[s_qbase + i] = tile0 + s_order[s_off[NB - 1] + i];
     // One loop per bin, so that each material's code is register-allocated on its own.  A wave takes 64
     // consecutive entries of the bin per trip; lane 4q + m shades entry 16m + q of them, which makes load j
     // of the quad-cooperative accesses cover entries 16j .. 16j + 15.  The trip count is wave-uniform.
