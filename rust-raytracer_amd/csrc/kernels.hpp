@@ -2509,7 +2509,9 @@ __device__ inline bool shade_hit(const DScene& S, const BatchDesc& B, uint32_t b
 // background (camera.rs:264-266).  The tile reserves room for every entry that can scatter in the next
 // bounce's arrays with one global atomic, the paths that go on write their new ray and radiance map
 // there, and the few reserved entries left over (paths ended by camera.rs:291-293) are marked empty.
-#define CHIP_SHADE_TILE 1024
+#ifndef CHIP_SHADE_TILE
+#define CHIP_SHADE_TILE 2048  // (512 / 1024 / 2048 / 4096 measured on the sphere scene: shading 283 / 267 / 247 / 252 ms per frame over both streams)
+#endif
 // B0: the instantiation for bounce 0, whose entries are the batch's paths in order with their camera rays
 // recomputed and the identity as radiance map; kept apart so that neither variant pays registers for the other.
 // `pass`: which entries of the bounce this launch shades.
