@@ -429,6 +429,7 @@ def main():
             optional("cpu_baseline", lambda: cpu_baseline(args.width, args.depth, args.seed))
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # (rank 0 renders one more frame after the timed region: the others wait for it before the group goes)
         dist.destroy_process_group()
 
 
