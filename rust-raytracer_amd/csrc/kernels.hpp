@@ -24,6 +24,9 @@
 #ifndef CHIP_REFILL_THRESH_B0
 #define CHIP_REFILL_THRESH_B0 1  // the same for camera rays: never, so that a wave always computes 64 camera rays at a time
 #endif
+#ifndef CHIP_REFILL_THRESH_B0_INSTANCES
+#define CHIP_REFILL_THRESH_B0_INSTANCES 32  // ... except among instanced spheres, whose long descents from memory leave the early finishers idle for too long (lattice +4 %)
+#endif
 // The descent loop of the ordered traversal goes on while at least 1 / DEN of the wave's lanes that still have a ray
 // are at culling nodes (see traverse); 0 = until none is.  Measured per scene family: bare spheres gain the most
 // from a small share, sphere instances from a larger one, the variant with media a little, and the one for rotated
@@ -1972,7 +1975,7 @@ __global__ void __launch_bounds__(extend_block(F, CACHE), extend_min_waves(F, CA
     if (!__any(has) && exhausted) break;
     // 3. traverse until the rays are done or too few lanes are still busy
     if (has) traverse<F, true, CACHE, ORD>(S, C, node, r, 0.001, best_t, best, rng, st, 0, cnt,
-                                           (exhausted && w_next >= w_end) ? 0 : (B0 ? CHIP_REFILL_THRESH_B0 : CHIP_REFILL_THRESH));
+                                           (exhausted && w_next >= w_end) ? 0 : (B0 ? ((F & TF_NO_QUADROT) ? CHIP_REFILL_THRESH_B0_INSTANCES : CHIP_REFILL_THRESH_B0) : CHIP_REFILL_THRESH));
   }
   if (st.overflow) atomicOr(&P.errflag[0], 1u);
   // per-wave reduction of the traversal counters
