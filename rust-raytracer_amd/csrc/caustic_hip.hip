@@ -255,16 +255,19 @@ static uint32_t scene_features(const Flat& F) {
 static const uint32_t kMaxGridBlocksDef = 2048;
 static const uint32_t kMaxGridBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 
-// Largest path pool a render may use.  Every bounce of a batch is one round of kernel launches, and the
-// late bounces of a batch carry few paths, so batches are made as large as the frame allows: the
-// default of 2^28 path slots (260 B each, 70 GB) leaves that tail at a few per cent of a 1080p frame.
+// Largest path pools a render may use, all batches in flight together.  Every bounce of a batch is one round of kernel
+// launches, and the late bounces of a batch carry too few paths to fill the device, so batches are made as large as the
+// frame and the memory allow: up to 2^30 path slots (241 B each, 259 GB of an MI355X's 288 GiB; ensure_pool() takes less
+// when less is free), at most 2^29 per pool.  The 1080p / 1024 spp frame then runs as four batches of 256 strata; with
+// the earlier cap of 2^28 slots (16 batches) it took 425 ms instead of 347.
+static const size_t kPoolPathsMaxEach = (size_t)1 << 29;
 static size_t pool_capacity_max() {
   const char* e = getenv("CHIP_POOL_PATHS");
   if (e && *e) {
     long long v = atoll(e);
     if (v >= 4096) return (size_t)v;
   }
-  return (size_t)1 << 28;
+  return (size_t)1 << 30;
 }
 // (per-bounce arrays hold 1/16 more entries than the pool has path slots: PathPool::slack)
 static const size_t kBytesPerPathSlot = (2 * sizeof(PathRay) + sizeof(PathHit) + 2 * sizeof(PathMap) + sizeof(uint32_t)) * 17 / 16 + sizeof(float4);
@@ -702,7 +705,7 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
     if (e_streams && *e_streams) lanes_wanted = std::max(1, std::min(kMaxLanes, atoi(e_streams)));
     if (want_total < overlap_min) lanes_wanted = 1;
     n_lanes = (int)std::min<uint32_t>((uint32_t)lanes_wanted, std::max<uint32_t>(pl.s_count, 1));
-    const size_t max_each = pool_capacity_max() / (size_t)n_lanes;
+    const size_t max_each = std::min(pool_capacity_max() / (size_t)n_lanes, kPoolPathsMaxEach);
     const size_t want_each = (size_t)pl.rw * pl.rh * ((std::max<uint32_t>(pl.s_count, 1) + n_lanes - 1) / n_lanes);
     for (int k = 0; k < n_lanes; k++)
       if (ensure_pool(s, D, k, want_each, max_each, mem_share)) return -1;
@@ -724,7 +727,14 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
     const uint32_t bh = std::min(band_rows, pl.rh - by);
     const uint32_t npix = pl.rw * bh;
     uint32_t spb = std::max<uint32_t>(1, (uint32_t)(cap / npix));
-    if (o->strata_per_batch) spb = std::min(spb, o->strata_per_batch);
+    if (o->strata_per_batch) {
+      spb = std::min(spb, o->strata_per_batch);
+    } else if (n_lanes >= 2 && pl.s_count > spb) {
+      // batches of equal size, as many as a multiple of the batches in flight: no lane is left with one batch more
+      uint32_t nb = (pl.s_count + spb - 1) / spb;
+      nb = (nb + (uint32_t)n_lanes - 1) / (uint32_t)n_lanes * (uint32_t)n_lanes;
+      spb = (pl.s_count + nb - 1) / nb;
+    }
     for (uint32_t sb0 = 0; sb0 < pl.s_count; sb0 += spb) {
       Batch bt;
       BatchDesc& B = bt.B;
