@@ -282,7 +282,8 @@ def main():
         achieved = ops_per_seg * seg / (ms_trace * 1e-3) / 1e12 if (usable and ms_trace > 0) else None
         roofline = {
             "kernel": "k_first_small<true> (bounce 0: camera ray, closest hit and the lean material code in one kernel) + k_extend_small<false> (closest hit of "
-                      "later bounces): ordered traversal, compact form, f32 culling of 4-wide nodes, f64 sphere tests, scene tables in LDS",
+                      "later bounces) + k_tail_small<true> (the last bounces of a batch in one kernel): ordered traversal, compact form, f32 culling of 4-wide nodes, "
+                      "f64 sphere tests, scene tables in LDS",
             "bound": "valu",
             "achieved": achieved,
             "peak": VALU_PEAK_TLANEOPS,

@@ -536,6 +536,28 @@ static int launch_first_small(const DeviceState& D, const PathPool& P, const Ext
   else hipLaunchKernelGGL((k_first_small<false>), dim3(blocks), dim3(p.block), p.lds_bytes, st, D.dscene, P, B, p.cd, range);
   return 0;
 }
+// The tail of a batch in one kernel (k_tail_small), enqueued ahead of a bounce's ordinary launches: it takes the bounce
+// (and every bounce after it) if the bounce holds at most max_live entries, and does nothing otherwise.
+static int launch_tail_small(const DeviceState& D, const PathPool& P, const ExtendPlan& p, hipStream_t st, const BatchDesc& B, uint32_t bounce, bool fast,
+                             uint32_t max_live) {
+  static std::atomic<uint64_t> attr_done{0};
+  const uint64_t bit = 1ull << ((unsigned)D.device & 63u);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_tail_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_tail_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  if (p.block != (uint32_t)extend_block(0, true)) return fail("internal: traversal launch planned for another kernel variant");
+  uint32_t blocks = (std::min<uint32_t>(max_live, P.cap) + p.block - 1) / p.block;
+  blocks = std::max(1u, std::min(blocks, (uint32_t)D.n_cus));
+  // the literal form inside the kernel keeps its stack in the thread's spill slab: no more threads than slabs (the static
+  // pool of the no-allocation entry point has few)
+  blocks = std::min<uint32_t>(blocks, (uint32_t)(P.ovf_slabs / p.block));
+  if (blocks == 0u) return 0;
+  if (fast) hipLaunchKernelGGL((k_tail_small<true>), dim3(blocks), dim3(p.block), p.lds_bytes, st, D.dscene, P, B, bounce, p.cd, max_live);
+  else hipLaunchKernelGGL((k_tail_small<false>), dim3(blocks), dim3(p.block), p.lds_bytes, st, D.dscene, P, B, bounce, p.cd, max_live);
+  return 0;
+}
 template <uint32_t F, bool CACHE, bool ORD>
 static int launch_extend_t(const DeviceState& D, const PathPool& P, const ExtendPlan& p, uint32_t n_live_upper, hipStream_t st, const BatchDesc& B,
                            uint32_t bounce, uint32_t lit_pass) {
@@ -670,6 +692,10 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
   bool all_rich = !s->host.materials.empty();
   for (const DMaterial& m : s->host.materials) all_rich = all_rich && (m.flags & MF_RICH_TEX) != 0;
   const bool fused_first_ok = fused_first_possible(xplans, lean);
+  // bounces of at most this many entries are finished by k_tail_small (0 = never; small sphere scenes with lean shading)
+  uint32_t tail_paths = 1u << 22;
+  if (const char* e = getenv("CHIP_TAIL_PATHS")) { if (*e) tail_paths = (uint32_t)std::max(0LL, std::min(atoll(e), 1LL << 27)); }
+  static const uint32_t kTailFirstBounce = 1;  // (bounce 0 has no entries in memory: its paths are the batch)
   const bool lean_xform = solid_only && (feat & ~TF_NO_QUADROT) == (TF_QUADS | TF_XFORM) && s->flat.quads.empty() && s->flat.media.empty();
   // scenes of a few primitives, materials and lights: the shade kernel works from LDS copies of the record tables
   // (CHIP_NO_SHADE_TABLES=1 keeps them in memory: tests compare the two)
@@ -842,6 +868,13 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
       // bounce 0 of a small sphere scene with lean shading: one kernel traces and shades; the shade launch below then
       // only takes the rays that went through the literal queue (normally none: one block)
       const bool fused = bounce == 0 && fused_first_ok && !B.reference_order;
+      // once few paths are left, one kernel follows them to their ends (it declines while the bounce holds more)
+      if (tail_paths && fused_first_ok && !B.reference_order && bounce >= kTailFirstBounce && L.live_upper > 0) {
+        if (launch_tail_small(D, P, xplans.full, L.st, B, bounce, !exact_shading, tail_paths)) {
+          bag.failed = true;
+          return -1;
+        }
+      }
       uint32_t waste = 0;
       if (launch_extend(D, P, xplans, L.live_upper, L.st, B, bounce, L.lit_expected, fused ? (exact_shading ? 1 : 2) : 0, &waste)) {
         bag.failed = true;

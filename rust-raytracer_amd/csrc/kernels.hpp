@@ -2973,6 +2973,235 @@ __global__ void __launch_bounds__(extend_block(0, true), 4) k_first_small(DScene
   }
 }
 
+// ------------------------------------------------------------------ the tail of a batch in one kernel (small sphere scenes)
+// From a dozen bounces on a batch holds too few paths to fill the device, and every further bounce still costs a round
+// of dependent launches: the last forty bounces of a batch take about 8 ms however few paths are left.  k_tail_small
+// takes the entries of one bounce, once they are few enough, and follows every one of those paths to its end: a lane
+// traces its ray (traverse_small, as k_extend_small does), shades the hit where it stands (the lean material code, as
+// k_first_small does), keeps the scattered ray and the composed radiance map in registers, and goes on with the next
+// bounce; a lane whose path has ended takes the next entry of the queue.  A path's random stream is keyed by (pixel,
+// stratum, bounce), and in the default shading mode the scattered direction is rounded to the floats a ray record would
+// have held, so every sample is the bit pattern the bounce-by-bounce kernels produce.
+// A ray the compact traversal does not take (a zero direction component, a descent deeper than its stack) is traced
+// right here by the literal form (tail_literal: the reference's own tree and order, its stack in the thread's spill slab).
+// The host enqueues the kernel ahead of a bounce's ordinary launches without knowing the live count: a launch that finds
+// more than `max_live` entries returns at once, and one that takes the bounce sets its entry count to zero when its last
+// block is done, so that the launches that follow find nothing to do.
+#define CHIP_CTR_TAIL_DONE 11
+__device__ __noinline__ void tail_literal(const DScene& S, TravRay& r, double& best_t, nref_t& best, uint32_t* slab, TravCounters& cnt, uint32_t* errflag) {
+  TravStack ts;
+  ts.lds = (lds_u2_t)0;  // (never addressed: no entry is kept in LDS)
+  ts.ovf = slab;
+  ts.sp = 0;
+  ts.overflow = 0;
+  ts.redo = 0;
+  ts.lds_cap = 0;
+  ts.stride8 = 0;
+  r.o = r.wo; r.d = r.wd;
+  ray_set_inv<false>(r);
+  best_t = INFINITY;
+  best = NREF_NONE;
+  nref_t node = S.root;
+  Rng rng;
+  rng.init(0, 0, 0, 0, 0, 0);
+  const NodeCache none{0, 0, 0, 0, 0, 0};
+  traverse<0, false, false, false>(S, none, node, r, 0.001, best_t, best, rng, ts, 0, cnt);
+  if (ts.overflow) atomicOr(errflag, 1u);
+}
+template <bool FAST>
+__global__ void __launch_bounds__(extend_block(0, true), 4) k_tail_small(DScene S, PathPool P, BatchDesc B, uint32_t bounce0, CacheDesc cd, uint32_t max_live) {
+  uint32_t* ctr = P.counters + (size_t)bounce0 * CHIP_CTR_STRIDE;
+  const uint32_t n_live = ctr[0];
+  if (n_live == 0u || n_live > max_live) return;  // (every block of the launch reads the same count: see the end of the kernel)
+  const NodeCache C{0u, (uint32_t)CHIP_WNODE_U4 * cd.n_bvh, cd.n_bvh, cd.n_sph, cd.n_bvh, cd.n_sph};
+  for (uint32_t i = threadIdx.x; i < cd.n_bvh; i += blockDim.x) {
+    const uint4* p = reinterpret_cast<const uint4*>(S.wnodes + i);
+#pragma unroll
+    for (int k = 0; k < 6; k++) g_lds[(uint32_t)CHIP_WNODE_U4 * i + k] = p[k];
+    const uint4 ch = p[6];
+    g_lds[(uint32_t)CHIP_WNODE_U4 * i + 6u] = make_uint4(small_ref(ch.x), small_ref(ch.y), small_ref(ch.z), small_ref(ch.w));
+  }
+  const uint32_t so = (uint32_t)CHIP_WNODE_U4 * cd.n_bvh;
+  for (uint32_t i = threadIdx.x; i < cd.n_sph; i += blockDim.x) {
+    const uint4* p = reinterpret_cast<const uint4*>(S.spheres + i);
+    g_lds[so + i] = p[0]; g_lds[so + cd.n_sph + i] = p[1]; g_lds[so + 2 * cd.n_sph + i] = p[2]; g_lds[so + 3 * cd.n_sph + i] = p[3];
+  }
+  __syncthreads();
+  const PathRay* ray_in = P.ray[bounce0 & 1];
+  const PathMap* map_in = P.st[bounce0 & 1];
+  uint32_t* cursor = &ctr[CHIP_CTR_CURSOR];
+  const uint32_t lane = __lane_id();
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  SmallStack st;
+  st.lds = (lds_u1_t)(g_lds + (CHIP_WNODE_U4 * cd.n_bvh + 4u * cd.n_sph)) + threadIdx.x;
+  st.overflow = 0;
+  st.sp = 0;
+  st.lds_cap = (int)cd.stack_entries;
+  st.stride4 = 4u * blockDim.x;
+  TravCounters cnt{0, 0};
+  uint32_t nseg = 0;
+  const uint32_t root = small_ref(S.ord_root);
+  const uint32_t max_depth = S.cam.max_depth;
+  // per-lane path state
+  bool has = false;
+  uint32_t id = 0, bnc = bounce0;
+  Affine f;
+  affine_identity(f);
+  TravRay r;
+  r.wo = r.wd = r.o = r.d = r.inv = mk(0, 0, 0);
+  r.time = 0;
+  r.best_mat = 0;
+  double best_t = INFINITY;
+  nref_t best = NREF_NONE;
+  uint32_t node = CHIP_SM_NONE;
+  uint32_t w_next = 0, w_end = 0;
+  bool exhausted = false;
+  // Takes the ray in r.wo / r.wd to the start of its traversal (or flags it for the literal form)
+#define CHIP_TAIL_START(hand_over)                                        \
+  {                                                                       \
+    r.o = r.wo; r.d = r.wd;                                               \
+    const bool ordinary_ = ray_set_inv<true>(r);                          \
+    r.capf = INFINITY;                                                    \
+    best_t = INFINITY;                                                    \
+    best = NREF_NONE;                                                     \
+    st.sp = 0;                                                            \
+    st.overflow = (!ordinary_ || (hand_over)) ? 1u : 0u;                  \
+    node = st.overflow ? CHIP_SM_NONE : root;                             \
+    has = true;                                                           \
+  }
+  for (;;) {
+    // 1. rays whose traversal is over: those the compact form gave up on are traced literally first
+    const bool fin = has && node == CHIP_SM_NONE;
+    {
+      const bool lit = fin && st.overflow != 0u;
+      if (__any(lit)) {
+        if (lit) tail_literal(S, r, best_t, best, P.ovf + (size_t)gtid * (2 * CHIP_STACK_OVF), cnt, &P.errflag[0]);
+      }
+      st.overflow = fin ? 0u : st.overflow;
+    }
+    // 2. their hits are shaded where they stand (material/*.rs through shade_material; a miss takes the background)
+    if (__any(fin)) {
+      nseg += fin ? 1u : 0u;
+      const uint32_t kind = !fin ? 0xFFu : (best == NREF_NONE ? (uint32_t)MK_COUNT : MATK_KIND(r.best_mat));
+      float xw[3] = {0.f, 0.f, 0.f}, klo = 0.f, khi = 0.f;
+      bool cont = false;
+      V3 no = mk(0, 0, 0), nd = mk(0, 0, 0);
+      HitOut hrec;
+      hrec.pt = hrec.n = mk(0, 0, 0);
+      hrec.u = hrec.v = 0.0;
+      hrec.front = false;
+      hrec.mat = 0;
+      hrec.leaf_id = -1;
+      uint32_t pixel = 0, stratum = 0;
+      if (fin && best != NREF_NONE) {
+        // HitRecord of the closest sphere (sphere.rs:122-134, object/mod.rs:44-51) from its LDS copy: reconstruct<0, FAST>'s arithmetic
+        const uint32_t i = C.sph_off + NREF_INDEX(best);
+        const uint4 a = lds_read4(i), b = lds_read4(i + C.cap_sph), c = lds_read4(i + 2 * C.cap_sph), d = lds_read4(i + 3 * C.cap_sph);
+        const V3 c0 = mk(u2d(a.x, a.y), u2d(a.z, a.w), u2d(b.x, b.y)), dc = mk(u2d(b.z, b.w), u2d(c.x, c.y), u2d(c.z, c.w));
+        const double radius = u2d(d.x, d.y);
+        hrec.pt = r.wo + (best_t * r.wd);
+        const V3 center = c0 + (r.time * dc);
+        const V3 outward = FAST ? (hrec.pt - center) * fast_rcp(radius) : (hrec.pt - center) / radius;
+        hrec.front = dot(r.wd, outward) < 0.0;
+        hrec.n = hrec.front ? outward : -outward;
+        hrec.mat = MATK_ID(r.best_mat);
+        uint32_t x_, y_;
+        slot_to_path(B, S.cam, id, x_, y_, pixel, stratum);
+      }
+#define CHIP_TAIL_KIND(KIND)                                                                                           \
+  if (__any(kind == KIND)) {                                                                                           \
+    if (kind == KIND)                                                                                                  \
+      cont = shade_material<KIND, FAST, true, false, false>(S, B, bnc, pixel, stratum, S.materials[hrec.mat], hrec, r.wd, xw, klo, khi, no, nd); \
+  }
+      CHIP_TAIL_KIND(MK_LAMBERTIAN)
+      CHIP_TAIL_KIND(MK_METAL)
+      CHIP_TAIL_KIND(MK_DIELECTRIC)
+      CHIP_TAIL_KIND(MK_DIFFUSE_LIGHT)
+      CHIP_TAIL_KIND(MK_ISOTROPIC)
+#undef CHIP_TAIL_KIND
+      if (kind == MK_COUNT) {
+        xw[0] = (float)S.cam.background[0]; xw[1] = (float)S.cam.background[1]; xw[2] = (float)S.cam.background[2];
+      }
+      if (fin) {
+        if (cont) {
+          affine_compose(f, xw, klo, khi);
+          xw[0] = 0.f; xw[1] = 0.f; xw[2] = 0.f;
+          cont = !(bnc + 1u >= max_depth);  // camera.rs:259-261
+        }
+        if (!cont) {
+          finish_path(P, id, f, xw);
+          has = false;
+        } else {
+          // the next segment of the same path: the ray a record of the next bounce would have held
+          r.wo = no;
+          if (FAST) r.wd = mk((double)(float)nd.x, (double)(float)nd.y, (double)(float)nd.z);
+          else r.wd = nd;
+          bnc++;
+          CHIP_TAIL_START(false)
+        }
+      }
+    }
+    // 3. lanes without a path take the next entries of the queue
+    {
+      const unsigned long long need = __ballot(!has);
+      if (need && !exhausted) {
+        if (w_next >= w_end) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(cursor, 64u);
+          base = __builtin_amdgcn_readfirstlane(base);
+          w_next = base;
+          w_end = min(base + 64u, n_live);
+          if (base >= n_live) { exhausted = true; w_end = w_next; }
+        }
+        const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
+        const uint32_t avail = w_end - w_next;
+        if (!has && rank < avail) {
+          const uint32_t entry = w_next + rank;
+          uint32_t rid = 0;
+          ray_load(ray_in, entry, B.ray48 != 0u, r.wo, r.wd, r.time, rid);
+          if (rid != CHIP_DEAD_ID) {  // (an entry reserved by the last shading pass but left empty is passed over)
+            const uint4* pm = reinterpret_cast<const uint4*>(map_in + entry);
+            const uint4 m0 = pm[0], m1 = pm[1];
+            id = m0.x & ~CHIP_MAP_CLAMPED;
+            f.clamped = m0.x & CHIP_MAP_CLAMPED;
+            f.b[0] = __uint_as_float(m0.y); f.b[1] = __uint_as_float(m0.z); f.b[2] = __uint_as_float(m0.w);
+            f.bound[0] = __uint_as_float(m1.x); f.bound[1] = __uint_as_float(m1.y); f.bound[2] = __uint_as_float(m1.z);
+            bnc = bounce0;
+#ifdef CHIP_TEST_HAND_OVER
+            CHIP_TAIL_START(entry % CHIP_TEST_HAND_OVER == 0u)
+#else
+            CHIP_TAIL_START(false)
+#endif
+          }
+        }
+        w_next += min((uint32_t)__popcll(need), avail);
+      }
+    }
+    if (!__any(has) && exhausted) break;
+    // 4. closest hits, until too few lanes are still at it
+    //    (a lane that finishes goes on with its path's next ray, so the wave comes back for it as it would for a refill;
+    //    once the queue is used up, when a quarter of the paths the wave still holds are waiting)
+    const int busy_thresh = exhausted ? (int)((uint32_t)__popcll(__ballot(has)) * 3u / 4u) : CHIP_REFILL_THRESH;
+    if (has && node != CHIP_SM_NONE) traverse_small<true>(S, C, node, r, 0.001, best_t, best, st, cnt, busy_thresh);
+  }
+#undef CHIP_TAIL_START
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt.bvh += __shfl_down(cnt.bvh, off);
+    cnt.prim += __shfl_down(cnt.prim, off);
+    nseg += __shfl_down(nseg, off);
+  }
+  if (lane == 0 && nseg) {
+    atomicAdd(&P.stats[0], (unsigned long long)nseg);
+    atomicAdd(&P.stats[1], (unsigned long long)cnt.bvh);
+    atomicAdd(&P.stats[2], (unsigned long long)cnt.prim);
+  }
+  // the last block to finish takes the bounce's entries off the books: the launches that follow find none
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (atomicAdd(&ctr[CHIP_CTR_TAIL_DONE], 1u) == gridDim.x - 1u) ctr[0] = 0u;
+  }
+}
+
 // Adds this batch's finished samples into the rectangle's f32 radiance sum, strata in
 // ascending order per pixel (camera.rs:335-341's `pixel_color += sample`).
 __global__ void __launch_bounds__(CHIP_BLOCK) k_accumulate(PathPool P, BatchDesc B, float* sum_rgb) {

@@ -944,6 +944,41 @@ def test_shading_from_lds_tables_equals_shading_from_memory(pkg, gpu, oracle, mo
 
 
 @pytest.mark.gpu
+def test_tail_of_a_batch_in_one_kernel_equals_bounce_by_bounce(pkg, gpu, oracle, monkeypatch):
+    """Once a bounce of a small sphere scene holds few enough entries (CHIP_TAIL_PATHS, 4 M by default), one kernel follows
+    those paths to their ends: it traces, shades in place and keeps the scattered ray in registers (k_tail_small).  Every
+    sample must be the bit pattern the bounce-by-bounce kernels produce (CHIP_TAIL_PATHS=0), in both shading modes, with
+    most descents overflowing the compact form's stack (the literal form inside the kernel then traces them) and at depths
+    that end paths inside the kernel by camera.rs:259-261; the frame is also compared with the oracle's."""
+    X = pkg.bindings.RENDER_EXACT_SHADING
+    for name, kw, seed in (("random_spheres", dict(width=400, spp=9, depth=50), 1), ("random_spheres", dict(width=160, spp=16, depth=7), 2),
+                           ("three_spheres", dict(width=200, spp=9, depth=50), 3), ("random_spheres", dict(width=1920, spp=4, depth=50), 4)):
+        sc = pkg.scenes.build(gpu, name, **kw)
+        for stack in (None, "4"):
+            if stack:
+                monkeypatch.setenv("CHIP_SMALL_STACK", stack)
+            for flags in (0, X):
+                monkeypatch.delenv("CHIP_TAIL_PATHS", raising=False)
+                tail, _, st1 = sc.render_frame(seed=seed, flags=flags)
+                monkeypatch.setenv("CHIP_TAIL_PATHS", "0")
+                plain, _, st2 = sc.render_frame(seed=seed, flags=flags)
+                monkeypatch.setenv("CHIP_TAIL_PATHS", "3000")  # (the kernel takes over late, with a handful of paths)
+                late, _, st3 = sc.render_frame(seed=seed, flags=flags)
+                monkeypatch.delenv("CHIP_TAIL_PATHS")
+                assert st1["segments"] == st2["segments"] == st3["segments"] and st1["paths"] == st2["paths"], (name, kw, stack, flags)
+                assert np.array_equal(tail.view(np.uint32), plain.view(np.uint32)), (name, kw, stack, flags)
+                assert np.array_equal(late.view(np.uint32), plain.view(np.uint32)), (name, kw, stack, flags)
+            monkeypatch.delenv("CHIP_SMALL_STACK", raising=False)
+    so = pkg.scenes.build(oracle, "random_spheres", width=96, spp=4, depth=50)
+    sg = pkg.scenes.build(gpu, "random_spheres", width=96, spp=4, depth=50)
+    img_o, _, st_o = so.render_frame(seed=7, sum_dtype=np.float64)
+    img_g, _, st_g = sg.render_frame(seed=7, flags=X)
+    assert st_g["segments"] == st_o["segments"]
+    diff = np.abs(img_g.astype(np.float64) - img_o)
+    assert (diff > 1e-3 * (1.0 + np.abs(img_o))).mean() < 2e-3
+
+
+@pytest.mark.gpu
 def test_literal_hand_over_of_every_fifth_ray(pkg, gpu):
     """The ordered traversal hands a ray it cannot take (a zero direction component, a descent deeper than the compact
     form's stack) to the literal traversal, which runs as a pass of its own after it: a ray or two per frame in the

