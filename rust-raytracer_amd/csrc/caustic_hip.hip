@@ -874,6 +874,13 @@ static int render_into(chip_scene* s, DeviceState& D, const chip_render_opts* o,
           bag.failed = true;
           return -1;
         }
+        if (L.live_upper <= tail_paths && (size_t)P.ovf_slabs >= xplans.full.block) {
+          // the bounce cannot hold more than the kernel takes: the batch ends here, with no launch left to enqueue
+          if (time_kernels && (stamp() || stamp())) return -1;
+          n_trace_launches++;
+          L.bounce = cam.max_depth;
+          break;
+        }
       }
       uint32_t waste = 0;
       if (launch_extend(D, P, xplans, L.live_upper, L.st, B, bounce, L.lit_expected, fused ? (exact_shading ? 1 : 2) : 0, &waste)) {

@@ -2988,7 +2988,14 @@ __global__ void __launch_bounds__(extend_block(0, true), 4) k_first_small(DScene
 // more than `max_live` entries returns at once, and one that takes the bounce sets its entry count to zero when its last
 // block is done, so that the launches that follow find nothing to do.
 #define CHIP_CTR_TAIL_DONE 11
-__device__ __noinline__ void tail_literal(const DScene& S, TravRay& r, double& best_t, nref_t& best, uint32_t* slab, TravCounters& cnt, uint32_t* errflag) {
+// (takes the two tables and the root rather than the scene: an out-of-line call with the whole DScene would put it, and
+// with it the caller's every access to it, into scratch memory)
+__device__ __noinline__ void tail_literal(const DBvhNode* bvh, const DSphere* spheres, nref_t scene_root, TravRay& r, double& best_t, nref_t& best,
+                                          uint32_t* slab, TravCounters& cnt, uint32_t* errflag) {
+  DScene S{};
+  S.bvh = bvh;
+  S.spheres = spheres;
+  S.root = scene_root;
   TravStack ts;
   ts.lds = (lds_u2_t)0;  // (never addressed: no entry is kept in LDS)
   ts.ovf = slab;
@@ -3075,7 +3082,7 @@ __global__ void __launch_bounds__(extend_block(0, true), 4) k_tail_small(DScene 
     {
       const bool lit = fin && st.overflow != 0u;
       if (__any(lit)) {
-        if (lit) tail_literal(S, r, best_t, best, P.ovf + (size_t)gtid * (2 * CHIP_STACK_OVF), cnt, &P.errflag[0]);
+        if (lit) tail_literal(S.bvh, S.spheres, S.root, r, best_t, best, P.ovf + (size_t)gtid * (2 * CHIP_STACK_OVF), cnt, &P.errflag[0]);
       }
       st.overflow = fin ? 0u : st.overflow;
     }
