@@ -10,3 +10,5 @@ run "CHIP_LDS_STACK=2 CHIP_NO_LDS_CACHE=1" CHIP_LDS_STACK=2 CHIP_NO_LDS_CACHE=1
 run "CHIP_POOL_PATHS=8192 CHIP_STREAMS=3 CHIP_LDS_STACK=3" CHIP_POOL_PATHS=8192 CHIP_STREAMS=3 CHIP_LDS_STACK=3
 run "CHIP_NO_FUSED_FIRST=1 (bounce 0 in two kernels)" CHIP_NO_FUSED_FIRST=1
 run "CHIP_NO_SHADE_TABLES=1 (record tables left in memory for the shade kernels)" CHIP_NO_SHADE_TABLES=1
+run "CHIP_TAIL_PATHS=0 (every bounce in its own launches)" CHIP_TAIL_PATHS=0
+run "CHIP_TAIL_PATHS=2000 CHIP_SMALL_STACK=4 (the tail kernel takes over late; most of its rays go through the literal form inside it)" CHIP_TAIL_PATHS=2000 CHIP_SMALL_STACK=4
