@@ -1,3 +1,5 @@
+"""Times one rank's share of the headline frame (every n-th stratum of every pixel, no reduce) for jobs of 8, 4 and 2 ranks on this GPU.
+usage: [CHIP_STREAMS=..] [CHIP_POOL_PATHS=..] [CHIP_TAIL_PATHS=..] share_time.py"""
 import importlib, os, sys, time
 import torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
