@@ -1104,6 +1104,13 @@ static int upload_scene(chip_scene* s, DeviceState& D, const Flat& F) {
   T.has_lights = F.has_lights;
   T.lights_is_group = F.lights_is_group;
   T.literal_only = F.loose_geometry;
+  T.moving_spheres = 0;
+  for (const DSphere& sp : F.spheres)
+    for (int i = 0; i < 3; i++) {
+      uint64_t bits;
+      memcpy(&bits, &sp.dc[i], 8);
+      if (bits != 0) T.moving_spheres = 1;
+    }
   T.cam = s->host.cam;
   D.uploaded = true;
   return 0;

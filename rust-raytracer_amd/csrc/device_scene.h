@@ -2,6 +2,7 @@
 // All geometry is f64 (the reference computes in f64 and hit/miss decisions must
 // agree with it); radiance state and the framebuffer are f32.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 // A node reference: kind in the top 4 bits, index into that kind's table below.
@@ -103,19 +104,25 @@ struct DGroup {
 
 struct alignas(128) DTranslate {
   double off[3];
+  // With only_sphere (the sphere, when all the Translate holds is one sphere, directly or as a Group's only child; else
+  // NREF_NONE): that sphere's geometry and mat word, so that testing the instance reads this one 128-byte record instead
+  // of two records one after the other; and of this record its first half only, unless some sphere of the scene moves
+  // (each lane of a wave reads a record of its own, so a test costs what the number of 16-byte words it asks for costs).
+  double sc[3], sr;
+  nref_t only_sphere;
+  uint32_t sphere_mat;
+  double sdc[3];
   nref_t child;
   nref_t parent_xform;             // innermost transform ancestor of this node, or NREF_NONE
   uint32_t chain_first, chain_len;  // this node's root->self transform chain in xchain[]
-  nref_t only_sphere;  // the sphere, when all the Translate holds is one sphere (directly or as a Group's only child); else NREF_NONE
   // Where a traversal that enters this node continues: through a run of nested instances (each the other's only
   // content, e.g. Translate(Rotate(Box))) straight into the innermost one's space (enter_xform) and child.
   nref_t enter_xform, enter_child;
   // Where the ordered traversal continues instead of enter_child: the same node, unless that is a Group, whose
   // children it finds in a culling tree of their own.
   nref_t ord_child;
-  uint32_t sphere_mat;  // with only_sphere: that sphere's mat word and, below, its geometry, so that testing the
-  double sc[3], sdc[3], sr;  // instance reads this one 128-byte record instead of two records one after the other
 };
+static_assert(sizeof(DTranslate) == 128 && offsetof(DTranslate, sdc) == 64, "a fused instance test reads the first 64 bytes");
 
 struct alignas(8) DRotate {
   double m[9];  // row-major rotation; the inverse is its transpose (rotate.rs:52-68)
@@ -249,5 +256,8 @@ struct DScene {
   // disc.rs:25-35): the reference then finds it through whichever enclosing boxes the ray happens to cross, so every
   // ray replays the reference's visiting order instead of culling by child boxes.
   uint32_t literal_only;
+  // Some sphere's centre moves (sphere.rs:28-45).  When none does, every DSphere::dc and DTranslate::sdc is +0.0 and
+  // the traversal of instanced spheres leaves those words unread.
+  uint32_t moving_spheres;
   DCamera cam;
 };

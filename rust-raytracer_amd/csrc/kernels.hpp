@@ -937,7 +937,12 @@ __device__ void traverse(const DScene& S, const NodeCache& C, nref_t& node, Trav
       V3 toff = ld3(t.off);
       SphereRec sp;
       sp.c[0] = t.sc[0]; sp.c[1] = t.sc[1]; sp.c[2] = t.sc[2];
-      sp.dc[0] = t.sdc[0]; sp.dc[1] = t.sdc[1]; sp.dc[2] = t.sdc[2];
+      // (a scene without moving spheres: the same arithmetic on +0.0, without the record's second half)
+      sp.dc[0] = sp.dc[1] = sp.dc[2] = 0.0;
+      if (!(F & TF_NO_QUADROT) || S.moving_spheres) {
+        if (F & TF_NO_QUADROT) asm volatile("" ::: "memory");  // (keeps these loads on this side of the branch)
+        sp.dc[0] = t.sdc[0]; sp.dc[1] = t.sdc[1]; sp.dc[2] = t.sdc[2];
+      }
       sp.r = t.sr;
       sp.mat = t.sphere_mat;
       // Instanced-sphere scenes: everything the test below reads is asked for here, before the branch on what the
